@@ -1,0 +1,160 @@
+#!/usr/bin/env python3
+"""Headline benchmark: training images/sec (fwd + bwd + AdamW step), HRFormer-small + fusion head, 256x192, bf16.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]        # N>1: launched by torch.distributed.run, one rank per GPU
+
+Prints ONE JSON line on rank 0 (contract in the task statement).  Synthetic device-resident batches (SURVEY §8d,
+seed 1234+rank), B=64 per GPU (weak scaling), DropPath on, BN in train mode, every parameter updated.
+Extra objects: `roofline` (dominant hand-written HIP kernel, timed live with HIP events on its launch stream),
+`cpu_baseline` (the CPU oracle = parity-pinned port of the reference, timed on this host's cores, rank 0 / N=1 only),
+`impl` (which network ops run as HIP kernels vs ATen stop-gaps — see nnops.IMPL).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+PER_GPU_BATCH = 64
+INPUT_SIZE, HEATMAP_SIZE, K = (192, 256), (48, 64), 17
+
+
+def time_kernel(fn, iters=20, warmup=3):
+    """Average device time of `fn()` (one launch sequence on torch's current stream == the stream the C-ABI launches on)."""
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def roofline_of_dominant_kernel(batch, out):
+    """Dominant *hand-written* kernel of the step today: k_floss_bwd (pk_fusion_loss_bwd), HBM-bound.
+    Algorithmic bytes per launch = read heatmaps + target, write d_heatmaps + d_variances + d_offsets(2 planes)
+    = 6 maps x B*K*H*W*4 B."""
+    from infantposeestimation_gaussianbias_amd import hipops
+    from infantposeestimation_gaussianbias_amd._lib import call, stream_ptr
+    hm, off, var = (out[k].detach().float().contiguous() for k in ("heatmaps", "offsets", "variances"))
+    B, Kk, H, W = hm.shape
+    lam = torch.tensor([1.0, 1.0, 0.5, 0.1, 0.05, 0.05], device=hm.device)
+    ws = torch.empty(hipops.loss_ws_floats(B, Kk), device=hm.device)
+    losses = torch.empty(7, device=hm.device)
+    tgt, w, gt = batch["target"], batch["target_weight"], batch["keypoints"]
+    call("pk_fusion_loss_fwd", hm, off, var, tgt, w, gt, ws, losses, B, Kk, H, W, float(INPUT_SIZE[0]), float(INPUT_SIZE[1]), 2.0, lam, stream_ptr())
+    dhm, doff, dvar = torch.empty_like(hm), torch.empty_like(off), torch.empty_like(var)
+
+    def launch():
+        call("pk_fusion_loss_bwd", hm, off, var, tgt, w, ws, None, dhm, doff, dvar, B, Kk, H, W, 2.0, lam, stream_ptr())
+    sec = time_kernel(launch)
+    alg_bytes = 6 * B * Kk * H * W * 4
+    achieved = alg_bytes / sec / 1e9
+    return {"kernel": "k_floss_bwd", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "us_per_launch": round(sec * 1e6, 2),
+            "algorithmic_bytes": alg_bytes}
+
+
+def cpu_baseline():
+    """CPU oracle train step (B=8: ~2 s/step on 8 cores -> 1 warm-up + 3 timed steps stays within ~10-30 s)."""
+    import json as _json
+    from oracle import train_step as ots
+    with open(os.path.join(ROOT, "tests", "golden", "state_keys.json")) as f:
+        keys = _json.load(f)
+    cores = os.cpu_count() or 1
+    ips, threads = ots.time_train_steps(keys["hrformer_small_fusion"], keys["hrformer_small_fusion#params"], B=8, steps=3, warmup=1,
+                                        input_size=INPUT_SIZE, heatmap_size=HEATMAP_SIZE, K=K, threads=cores)
+    return {"value": round(ips, 3), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "HRFormer-small fusion 256x192 train step (fwd+bwd+AdamW), fp32 PyTorch-CPU oracle, B=8, 1 warm-up + 3 timed steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    if args.gpus != world and rank == 0:
+        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+
+    from infantposeestimation_gaussianbias_amd import engine, nnops
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+
+    torch.manual_seed(42)
+    cfg = get_config("hrformer_small")
+    cfg.train.batch_size = PER_GPU_BATCH
+    model = build_model(cfg).to(dev)
+    trainer = engine.Trainer(model, cfg, iters_per_epoch=1000)
+    batch = synthetic_batch(PER_GPU_BATCH, INPUT_SIZE, HEATMAP_SIZE, K, 2.0, dev, seed=1234 + rank)
+
+    out = None
+    for _ in range(args.warmup):
+        out = trainer.step(batch)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = trainer.step(batch)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    loss = float(out["loss"])
+
+    if rank == 0:
+        roof = roofline_of_dominant_kernel(batch, out)
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline()
+        n_hip = sum(v == "hip" for v in nnops.IMPL.values())
+        line = {
+            "metric": "images/sec (train fwd+bwd) HRFormer-S 256x192", "value": round(PER_GPU_BATCH * world * args.steps / dt, 2),
+            "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "HRFormer-small + fusion head, 256x192 -> 64x48, K=17, train step fwd+bwd+AdamW, DropPath 0.1, BN train",
+                       "global_batch": PER_GPU_BATCH * world, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
+            "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
+            "impl": dict(nnops.IMPL, loss="hip", target="hip", decode="hip", adamw="hip"),
+            "impl_note": f"{n_hip}/{len(nnops.IMPL)} network op groups are hand-written HIP; 'aten' entries are PyTorch-ROCm stop-gaps",
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

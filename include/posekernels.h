@@ -1,0 +1,111 @@
+/* libposekernels — C-ABI of the MI355X (gfx950) pose-estimation hot path.
+ *
+ * The reference (MarkJhonBao/InfantPoseEstimation_GaussianBias) is pure Python/PyTorch and has NO
+ * FFI/plugin boundary of its own; the Python class/function surface is its interface.
+ * This header is therefore the boundary this build defines underneath that surface: every entry point
+ * replaces one group of ATen calls made by a reference function, cited as (file:line) below.
+ *
+ * Conventions (all entries):
+ *   - extern "C", plain pointers and sizes; no C++/torch types.
+ *   - every pointer is a BORROWED DEVICE pointer (caller allocates inputs, outputs and workspaces);
+ *     the library allocates nothing and keeps no state besides a thread-local error string.
+ *   - asynchronous on `stream` (a hipStream_t passed as void*); no internal synchronisation; graph-capturable.
+ *   - returns 0 on success, a negative PK_ERR_* on argument validation failure (nothing launched),
+ *     or a positive hipError_t from the launch.  Never throws, never aborts.
+ *   - layouts: "maps" are (B,K,H,W) fp32 contiguous; features are NHWC; bf16 is the 16-bit upper half of fp32.
+ */
+#ifndef POSEKERNELS_H
+#define POSEKERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PK_OK 0
+#define PK_ERR_INVALID (-1)     /* bad shape / null pointer / misalignment */
+#define PK_ERR_UNSUPPORTED (-2) /* shape outside what the kernels are built for */
+
+#define PK_DT_F32 0
+#define PK_DT_BF16 1
+
+int pk_version(void);                      /* 10000*major + 100*minor + patch */
+const char* pk_last_error_string(void);    /* thread-local; valid until the next failing call on this thread */
+
+/* ---- T1: COCOPoseDataset._generate_target (datasets/coco_dataset.py:185-250), batched ------------------
+ * keypoints (B,K,2) f32 input-px; visible (B,K) f32 (COCO v: 0/1/2); lut = host-built patch values indexed
+ * by integer d2=dx^2+dy^2 (lut_len entries; built with the reference's own float32 numpy expression so the
+ * result is bit-exact); patch side n, centre c; reach = 3*sigma; stride = input/heatmap size (double).
+ * Writes EVERY element of target (B,K,Hh,Wh) and weight (B,K,1).                                          */
+int pk_gaussian_target(const float* keypoints, const float* visible, const float* lut, int lut_len,
+                       float* target, float* weight, int B, int K, int Hh, int Wh,
+                       double stride_x, double stride_y, double reach, int patch_n, int patch_c, void* stream);
+
+/* ---- T2: GenerateTarget (data/pose_transforms.py:385-457): dense sub-pixel Gaussian, weight 0/1 -------- */
+int pk_dense_target(const float* keypoints, const float* visible, float* heatmaps, float* weights,
+                    int B, int K, int Hh, int Wh, float scale_x, float scale_y, float sigma, void* stream);
+
+/* ---- D2/D3: argmax decoders.  mode 0: get_max_preds (utils/postprocess.py:10-34); mode 1: quarter shift of
+ * PoseEstimator.decode_heatmaps (models/pose_estimator.py:331-373); mode 2: Taylor sub-pixel of
+ * get_max_preds_with_subpixel (utils/postprocess.py:37-75).  index: first maximum (ties -> lowest index).    */
+int pk_argmax_decode(const float* heatmaps, int32_t* index, float* maxval, float* coords,
+                     int BK, int H, int W, int mode, void* stream);
+
+/* ---- D1: HeatmapRegressionHead.decode (models/fusion_head.py:309-365) = SoftArgmax2D (:24-71) +
+ * LocalGaussianRefinement (:74-128) + alpha blend (:169-170) + offset sampling.  alpha/fusion_weight are the
+ * RAW parameters (sigmoid applied inside), read from device memory.  offsets may be NULL (apply_offset=False). */
+int pk_softargmax_refine_decode(const float* heatmaps, const float* offsets, const float* alpha_param,
+                                const float* fusion_weight_param, float* coords, float* scores,
+                                int BK, int H, int W, int local_radius, void* stream);
+
+/* ---- D3 remainder (utils/postprocess.py:78-184,226-238,270-292) on (B,K,2) coordinates ----------------- */
+int pk_window_refine(const float* heatmaps, const float* coords_in, float* coords_out, int BK, int H, int W,
+                     int window, void* stream);                                  /* coordinate_refinement */
+int pk_fused_blend(const float* hp, const float* maxvals, const float* regression, float* out, int BK,
+                   float sx, float sy, float reg_scale, void* stream);           /* fused_decode tail */
+int pk_affine_coords(const float* coords, const float* center, const float* scale, float* out, int B, int K,
+                     float mul_x, float mul_y, const float* mask_maxvals, float threshold, void* stream);
+                     /* out = mask * coords * (scale*mul) + center - scale/2 : transform_preds / train.py:328-336 */
+
+/* ---- D4: flip-test merge (models/pose_estimator.py:303-319): out = (a + swapLR(flipW(b)))/2 ------------- */
+int pk_flip_merge(const float* a, const float* b_flipped, const int32_t* partner, float* out,
+                  int B, int K, int H, int W, void* stream);
+
+/* ---- L1/L2: FusionPoseLoss.forward (models/fusion_head.py:745-806 with :405-559, :637-743) ---------------
+ * stats: workspace of B*K*PK_LOSS_STAT floats + B*16*4 floats + 16 floats (see PK_LOSS_WS_FLOATS);
+ * losses: 7 floats (heatmap, offset, peak, variance, overlap, shape, total — already multiplied by lambdas). */
+#define PK_LOSS_STAT 24
+#define PK_LOSS_WS_FLOATS(B, K) ((B) * (K) * PK_LOSS_STAT + (B) * 16 * 4 + 16)
+int pk_fusion_loss_fwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
+                       const float* weight, const float* gt_keypoints, float* ws, float* losses,
+                       int B, int K, int H, int W, float in_w, float in_h, float sigma_t,
+                       const float* lambdas6, void* stream);
+int pk_fusion_loss_bwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
+                       const float* weight, const float* ws, const float* grad_total /*device scalar or NULL=1*/,
+                       float* d_heatmaps, float* d_offsets, float* d_variances,
+                       int B, int K, int H, int W, float sigma_t, const float* lambdas6, void* stream);
+
+/* ---- L3/L4: KeypointMSELoss (models/pose_estimator.py:102-143) and models/losses.py per-pixel losses ------
+ * kind 0: mean(((p-t)*w)^2)  [KeypointMSELoss]; 1: mean(w*(p-t)^2) [FusedPoseLoss mse];
+ * 2: mean(w*smoothl1(p-t)) [FusedPoseLoss smoothl1]; 3: JointsMSELoss (0.5*mean((p-t)^2 w^2)).
+ * partial: workspace of PK_REDUCE_BLOCKS floats.                                                            */
+#define PK_REDUCE_BLOCKS 1024
+int pk_pixel_loss_fwd(const float* pred, const float* target, const float* weight, float* partial, float* loss,
+                      int B, int K, int HW, int kind, void* stream);
+int pk_pixel_loss_bwd(const float* pred, const float* target, const float* weight, const float* grad_out,
+                      float* d_pred, int B, int K, int HW, int kind, void* stream);
+/* MorphologyShapeLoss statistics (models/losses.py:69-104): mean (BK,2), variance (BK,2) of hm/(sum+1e-8) */
+int pk_spatial_stats(const float* heatmaps, float* mean, float* var, int BK, int H, int W, void* stream);
+
+/* ---- S1: AdamW on one flat fp32 buffer (train.py:55-97 grouping; torch.optim.AdamW arithmetic) -----------
+ * decay_mask: 1 byte per element (1 = apply weight decay).  lr/step come from DEVICE scalars so a captured
+ * graph can be replayed while the schedule advances.  Also refreshes the bf16 compute copy (may be NULL).   */
+int pk_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, const uint8_t* decay_mask,
+                  uint16_t* param_bf16, int64_t n, const float* lr_dev, const int32_t* step_dev,
+                  float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* POSEKERNELS_H */

@@ -1,0 +1,78 @@
+"""ctypes binding of libposekernels.so (the C-ABI declared in include/posekernels.h).
+
+There is NO fallback: if the shared library is missing or a symbol cannot be resolved this module
+raises, and every op in the package fails with it.  Build with `python -c "import __graft_entry__ as g; g.build()"`
+or `make -C infantposeestimation_gaussianbias_amd/csrc`.
+"""
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libposekernels.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "posekernels.h")
+
+_CT = {
+    "int": ctypes.c_int, "float": ctypes.c_float, "double": ctypes.c_double, "int64_t": ctypes.c_int64,
+    "int32_t": ctypes.c_int32,
+}
+
+
+class PoseKernelError(RuntimeError):
+    pass
+
+
+def declared_symbols(header_path=HEADER_PATH):
+    """Parse `int pk_xxx(...)` prototypes out of the public header -> {name: [ctypes argtypes]}."""
+    with open(header_path) as f:
+        src = re.sub(r"/\*.*?\*/", " ", f.read(), flags=re.S)
+    out = {}
+    for m in re.finditer(r"\b(int|const char\s*\*)\s+(pk_\w+)\s*\(([^)]*)\)\s*;", src):
+        args = []
+        body = m.group(3).strip()
+        if body and body != "void":
+            for a in body.split(","):
+                a = a.strip()
+                if "*" in a:
+                    args.append(ctypes.c_void_p)
+                else:
+                    ty = a.replace("const", "").split()[0]
+                    args.append(_CT[ty])
+        out[m.group(2)] = (m.group(1), args)
+    return out
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise PoseKernelError(
+            f"{LIB_PATH} not found: the HIP extension is not built. There is no CPU/PyTorch fallback for the hot path; "
+            "run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc, cross-compiles gfx950 without a GPU).")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (ret, args) in declared_symbols().items():
+        fn = getattr(lib, name)          # AttributeError here == header/library mismatch: fail loudly
+        fn.argtypes = args
+        fn.restype = ctypes.c_char_p if "char" in ret else ctypes.c_int
+    return lib
+
+
+lib = _load()
+
+
+def call(name, *args):
+    """Invoke a pk_* entry; tensors are passed as data_ptr(), None as NULL. Raises on any non-zero status."""
+    conv = []
+    for a in args:
+        if a is None:
+            conv.append(None)
+        elif hasattr(a, "data_ptr"):
+            conv.append(a.data_ptr())
+        else:
+            conv.append(a)
+    rc = getattr(lib, name)(*conv)
+    if rc != 0:
+        raise PoseKernelError(f"{name} failed (code {rc}): {lib.pk_last_error_string().decode()}")
+
+
+def stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream

@@ -1,0 +1,376 @@
+// Target generation (T1, T2) and heatmap decoders (D1-D4). All HBM-bound, fp32, one workgroup per map.
+#include <stdarg.h>
+
+#include "pk_common.h"
+
+// ------------------------------------------------------------------------------------------------ errors
+static thread_local char g_err[512] = "";
+void pk_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* pk_last_error_string(void) { return g_err; }
+extern "C" int pk_version(void) { return 100; }
+
+// ================================================================================================ T1
+// One 256-thread workgroup per (b,k) map. Each thread redoes the (cheap) float64 index arithmetic, then the
+// block streams the whole map out with 16-byte stores: every element is written exactly once (zeros or LUT).
+__global__ void __launch_bounds__(256) k_gaussian_target(const float* __restrict__ kp, const float* __restrict__ vis,
+                                                         const float* __restrict__ lut, float* __restrict__ target,
+                                                         float* __restrict__ weight, int Hh, int Wh, double sx, double sy,
+                                                         double reach, int pn, int pc) {
+    const int map = blockIdx.x;
+    float w = vis[map];
+    bool draw = !(w < 0.5f);
+    int x_lo = 0, y_lo = 0, x_hi = 0, y_hi = 0;
+    if (draw) {
+        // float32 coordinate / float64 stride, then C truncation toward zero (Python int()).
+        const double mx = (double)kp[2 * map] / sx, my = (double)kp[2 * map + 1] / sy;
+        const double lim = 1.0e9;
+        x_lo = (int)fmin(fmax(mx - reach, -lim), lim);
+        y_lo = (int)fmin(fmax(my - reach, -lim), lim);
+        x_hi = (int)fmin(fmax(mx + reach + 1.0, -lim), lim);
+        y_hi = (int)fmin(fmax(my + reach + 1.0, -lim), lim);
+        if (x_lo >= Wh || y_lo >= Hh || x_hi < 0 || y_hi < 0) {
+            draw = false;
+            w = 0.f;
+        }
+    }
+    if (threadIdx.x == 0) weight[map] = w;
+    const int c0 = max(0, x_lo), c1 = min(x_hi, Wh), r0 = max(0, y_lo), r1 = min(y_hi, Hh);
+    float* out = target + (size_t)map * Hh * Wh;
+    const int n = Hh * Wh;
+    if ((Wh & 3) == 0) {
+        for (int i = threadIdx.x * 4; i < n; i += blockDim.x * 4) {
+            const int y = i / Wh, x = i - y * Wh;
+            float v[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int xx = x + j;
+                float val = 0.f;
+                if (draw && y >= r0 && y < r1 && xx >= c0 && xx < c1) {
+                    const int dx = xx - x_lo - pc, dy = y - y_lo - pc;
+                    val = lut[dx * dx + dy * dy];
+                }
+                v[j] = val;
+            }
+            *reinterpret_cast<float4*>(out + i) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += blockDim.x) {
+            const int y = i / Wh, x = i - y * Wh;
+            float val = 0.f;
+            if (draw && y >= r0 && y < r1 && x >= c0 && x < c1) {
+                const int dx = x - x_lo - pc, dy = y - y_lo - pc;
+                val = lut[dx * dx + dy * dy];
+            }
+            out[i] = val;
+        }
+    }
+}
+
+extern "C" int pk_gaussian_target(const float* keypoints, const float* visible, const float* lut, int lut_len, float* target,
+                                  float* weight, int B, int K, int Hh, int Wh, double stride_x, double stride_y,
+                                  double reach, int patch_n, int patch_c, void* stream) {
+    PK_REQUIRE(keypoints && visible && lut && target && weight, "pk_gaussian_target: null pointer");
+    PK_REQUIRE(B > 0 && K > 0 && Hh > 0 && Wh > 0, "pk_gaussian_target: bad shape B=%d K=%d H=%d W=%d", B, K, Hh, Wh);
+    PK_REQUIRE(stride_x > 0 && stride_y > 0 && reach > 0, "pk_gaussian_target: bad stride/reach");
+    const int far = patch_c > patch_n - 1 - patch_c ? patch_c : patch_n - 1 - patch_c;
+    PK_REQUIRE(patch_n > 0 && patch_c >= 0 && patch_c < patch_n && lut_len >= 2 * far * far + 1,
+               "pk_gaussian_target: LUT of %d entries too short for a %d-wide patch centred at %d", lut_len, patch_n, patch_c);
+    PK_REQUIRE((int)(2 * reach + 1) <= patch_n, "pk_gaussian_target: reach %.2f exceeds the %d-wide patch", reach, patch_n);
+    PK_REQUIRE(((uintptr_t)target & 15) == 0, "pk_gaussian_target: target must be 16-byte aligned");
+    hipLaunchKernelGGL(k_gaussian_target, dim3(B * K), dim3(256), 0, (hipStream_t)stream, keypoints, visible, lut, target, weight,
+                       Hh, Wh, stride_x, stride_y, reach, patch_n, patch_c);
+    return pk_launch_status("pk_gaussian_target");
+}
+
+// ================================================================================================ T2
+__global__ void __launch_bounds__(256) k_dense_target(const float* __restrict__ kp, const float* __restrict__ vis,
+                                                      float* __restrict__ hm, float* __restrict__ wts, int Hh, int Wh,
+                                                      float scx, float scy, float sigma) {
+    const int map = blockIdx.x;
+    const float cx = kp[2 * map] * scx, cy = kp[2 * map + 1] * scy;   // float32 multiply, as `scaled_keypoints[:,0] *= scale_w`
+    const bool on = vis[map] > 0.f && cx >= 0.f && cx < (float)Wh && cy >= 0.f && cy < (float)Hh;
+    if (threadIdx.x == 0) wts[map] = on ? 1.f : 0.f;
+    const float denom = 2.f * sigma * sigma;
+    float* out = hm + (size_t)map * Hh * Wh;
+    for (int i = threadIdx.x; i < Hh * Wh; i += blockDim.x) {
+        const int y = i / Wh, x = i - y * Wh;
+        float v = 0.f;
+        if (on) {
+            const float dx = (float)x - cx, dy = (float)y - cy;
+            v = fmaxf(0.f, expf(-(dx * dx + dy * dy) / denom));
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int pk_dense_target(const float* keypoints, const float* visible, float* heatmaps, float* weights, int B, int K,
+                               int Hh, int Wh, float scale_x, float scale_y, float sigma, void* stream) {
+    PK_REQUIRE(keypoints && visible && heatmaps && weights, "pk_dense_target: null pointer");
+    PK_REQUIRE(B > 0 && K > 0 && Hh > 0 && Wh > 0 && sigma > 0.f, "pk_dense_target: bad shape");
+    hipLaunchKernelGGL(k_dense_target, dim3(B * K), dim3(256), 0, (hipStream_t)stream, keypoints, visible, heatmaps, weights, Hh,
+                       Wh, scale_x, scale_y, sigma);
+    return pk_launch_status("pk_dense_target");
+}
+
+// ================================================================================================ argmax (D2, D3)
+struct ArgMax {
+    float v;
+    int i;
+};
+// torch.max semantics: NaN counts as the maximum; ties resolve to the lowest flat index.
+__device__ __forceinline__ bool am_better(float av, int ai, float bv, int bi) {
+    const bool an = av != av, bn = bv != bv;
+    if (an != bn) return an;
+    if (!an && av != bv) return av > bv;
+    return ai < bi;
+}
+__device__ __forceinline__ ArgMax am_wave(ArgMax a) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(a.v, o, 64);
+        const int oi = __shfl_xor(a.i, o, 64);
+        if (am_better(ov, oi, a.v, a.i)) {
+            a.v = ov;
+            a.i = oi;
+        }
+    }
+    return a;
+}
+__device__ __forceinline__ ArgMax am_block(const float* __restrict__ m, int n, float* sv, int* si) {
+    ArgMax a{-INFINITY, 0x7fffffff};
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = m[i];
+        if (am_better(v, i, a.v, a.i)) {
+            a.v = v;
+            a.i = i;
+        }
+    }
+    a = am_wave(a);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (lane == 0) {
+        sv[w] = a.v;
+        si[w] = a.i;
+    }
+    __syncthreads();
+    ArgMax r{sv[0], si[0]};
+    for (int k = 1; k < nw; ++k)
+        if (am_better(sv[k], si[k], r.v, r.i)) {
+            r.v = sv[k];
+            r.i = si[k];
+        }
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_argmax_decode(const float* __restrict__ hm, int32_t* __restrict__ index,
+                                                       float* __restrict__ maxval, float* __restrict__ coords, int H, int W,
+                                                       int mode) {
+    __shared__ float sv[4];
+    __shared__ int si[4];
+    const int map = blockIdx.x;
+    const float* m = hm + (size_t)map * H * W;
+    const ArgMax r = am_block(m, H * W, sv, si);
+    if (threadIdx.x != 0) return;
+    if (index) index[map] = r.i;
+    if (maxval) maxval[map] = r.v;
+    if (!coords) return;
+    const int x = r.i % W, y = r.i / W;
+    float fx = (float)x, fy = (float)y;
+    if (mode == 1) {  // quarter-pixel shift toward the larger neighbour; sign(0) = 0
+        if (x > 0 && x < W - 1 && y > 0 && y < H - 1) {
+            const float dx = m[y * W + x + 1] - m[y * W + x - 1], dy = m[(y + 1) * W + x] - m[(y - 1) * W + x];
+            fx += 0.25f * (float)((dx > 0.f) - (dx < 0.f));
+            fy += 0.25f * (float)((dy > 0.f) - (dy < 0.f));
+        }
+    } else if (mode == 2) {  // Taylor step, strict 1 < p < size-1, only where the 2nd difference is negative
+        if (x > 1 && x < W - 1 && y > 1 && y < H - 1) {
+            const float c = m[y * W + x];
+            const float l = m[y * W + x - 1], rr = m[y * W + x + 1], u = m[(y - 1) * W + x], d = m[(y + 1) * W + x];
+            const float dxx = (rr - 2.f * c) + l, dyy = (d - 2.f * c) + u;
+            if (dxx < 0.f) fx += fminf(fmaxf((rr - l) / (2.f * fabsf(dxx)), -0.5f), 0.5f);
+            if (dyy < 0.f) fy += fminf(fmaxf((d - u) / (2.f * fabsf(dyy)), -0.5f), 0.5f);
+        }
+    }
+    coords[2 * map] = fx;
+    coords[2 * map + 1] = fy;
+}
+
+extern "C" int pk_argmax_decode(const float* heatmaps, int32_t* index, float* maxval, float* coords, int BK, int H, int W,
+                                int mode, void* stream) {
+    PK_REQUIRE(heatmaps, "pk_argmax_decode: null heatmaps");
+    PK_REQUIRE(BK > 0 && H > 0 && W > 0 && (int64_t)H * W < 0x7fffffff, "pk_argmax_decode: bad shape");
+    PK_REQUIRE(mode >= 0 && mode <= 2, "pk_argmax_decode: mode %d", mode);
+    hipLaunchKernelGGL(k_argmax_decode, dim3(BK), dim3(256), 0, (hipStream_t)stream, heatmaps, index, maxval, coords, H, W, mode);
+    return pk_launch_status("pk_argmax_decode");
+}
+
+// ================================================================================================ D1
+__device__ __forceinline__ float bilinear_border(const float* __restrict__ p, int H, int W, float x, float y) {
+    x = fminf(fmaxf(x, 0.f), (float)(W - 1));
+    y = fminf(fmaxf(y, 0.f), (float)(H - 1));
+    const int x0 = (int)floorf(x), y0 = (int)floorf(y);
+    const float fx = x - (float)x0, fy = y - (float)y0;
+    const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);  // weight is 0 whenever the clamp bites
+    return p[y0 * W + x0] * (1.f - fx) * (1.f - fy) + p[y0 * W + x1] * fx * (1.f - fy) + p[y1 * W + x0] * (1.f - fx) * fy +
+           p[y1 * W + x1] * fx * fy;
+}
+
+__global__ void __launch_bounds__(256) k_softargmax_refine(const float* __restrict__ hm, const float* __restrict__ offsets,
+                                                           const float* __restrict__ alpha_p, const float* __restrict__ fw_p,
+                                                           float* __restrict__ coords, float* __restrict__ scores, int H, int W,
+                                                           int radius) {
+    __shared__ float red[16];
+    const int map = blockIdx.x, n = H * W;
+    const float* m = hm + (size_t)map * n;
+    float mx = -INFINITY;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) mx = fmaxf(mx, m[i]);
+    mx = block_max(mx, red);
+    float z = 0.f, sx = 0.f, sy = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float e = __expf(m[i] - mx);
+        const int y = i / W;
+        z += e;
+        sx += e * (float)(i - y * W);
+        sy += e * (float)y;
+    }
+    z = block_sum(z, red);
+    sx = block_sum(sx, red);
+    sy = block_sum(sy, red);
+    if (threadIdx.x != 0) return;
+    const float gx = sx / z, gy = sy / z;
+    // local softmax centroid of the clipped (2r+1)^2 patch around round-half-even(global)
+    const int px = (int)fminf(fmaxf(rintf(gx), 0.f), (float)(W - 1)), py = (int)fminf(fmaxf(rintf(gy), 0.f), (float)(H - 1));
+    const int x0 = max(0, px - radius), x1 = min(W, px + radius + 1), y0 = max(0, py - radius), y1 = min(H, py + radius + 1);
+    float lm = -INFINITY;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) lm = fmaxf(lm, m[y * W + x]);
+    float lz = 0.f, lx = 0.f, ly = 0.f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const float e = __expf(m[y * W + x] - lm);
+            lz += e;
+            lx += e * (float)x;
+            ly += e * (float)y;
+        }
+    const float a = 1.f / (1.f + __expf(-alpha_p[0]));
+    float cx = a * gx + (1.f - a) * (lx / lz), cy = a * gy + (1.f - a) * (ly / lz);
+    if (offsets) {
+        const float fw = 1.f / (1.f + __expf(-fw_p[0]));
+        const float* o = offsets + (size_t)map * 2 * n;
+        const float ox = bilinear_border(o, H, W, cx, cy), oy = bilinear_border(o + n, H, W, cx, cy);
+        cx += fw * ox;
+        cy += fw * oy;
+    }
+    coords[2 * map] = cx;
+    coords[2 * map + 1] = cy;
+    scores[map] = mx;
+}
+
+extern "C" int pk_softargmax_refine_decode(const float* heatmaps, const float* offsets, const float* alpha_param,
+                                           const float* fusion_weight_param, float* coords, float* scores, int BK, int H, int W,
+                                           int local_radius, void* stream) {
+    PK_REQUIRE(heatmaps && alpha_param && coords && scores, "pk_softargmax_refine_decode: null pointer");
+    PK_REQUIRE(!offsets || fusion_weight_param, "pk_softargmax_refine_decode: offsets given without fusion_weight");
+    PK_REQUIRE(BK > 0 && H > 0 && W > 0 && local_radius >= 0, "pk_softargmax_refine_decode: bad shape");
+    hipLaunchKernelGGL(k_softargmax_refine, dim3(BK), dim3(256), 0, (hipStream_t)stream, heatmaps, offsets, alpha_param,
+                       fusion_weight_param, coords, scores, H, W, local_radius);
+    return pk_launch_status("pk_softargmax_refine_decode");
+}
+
+// ================================================================================================ D3 tail
+__global__ void k_window_refine(const float* __restrict__ hm, const float* __restrict__ cin, float* __restrict__ cout, int BK,
+                                int H, int W, int window) {
+    const int map = blockIdx.x * blockDim.x + threadIdx.x;
+    if (map >= BK) return;
+    const float* m = hm + (size_t)map * H * W;
+    const int hw = window / 2;
+    const int x = (int)cin[2 * map], y = (int)cin[2 * map + 1];  // int() truncation
+    const int x0 = max(0, x - hw), x1 = min(W, x + hw + 1), y0 = max(0, y - hw), y1 = min(H, y + hw + 1);
+    float ox = cin[2 * map], oy = cin[2 * map + 1];
+    if (x1 > x0 && y1 > y0) {
+        float s = 0.f, ax = 0.f, ay = 0.f;
+        for (int yy = y0; yy < y1; ++yy)
+            for (int xx = x0; xx < x1; ++xx) {
+                const float v = m[yy * W + xx];
+                s += v;
+                ax += v * (float)xx;
+                ay += v * (float)yy;
+            }
+        ox = ax / (s + 1e-8f);
+        oy = ay / (s + 1e-8f);
+    }
+    cout[2 * map] = ox;
+    cout[2 * map + 1] = oy;
+}
+extern "C" int pk_window_refine(const float* heatmaps, const float* coords_in, float* coords_out, int BK, int H, int W,
+                                int window, void* stream) {
+    PK_REQUIRE(heatmaps && coords_in && coords_out && BK > 0 && H > 0 && W > 0 && window > 0, "pk_window_refine: bad argument");
+    hipLaunchKernelGGL(k_window_refine, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, heatmaps, coords_in, coords_out,
+                       BK, H, W, window);
+    return pk_launch_status("pk_window_refine");
+}
+
+// fused_decode tail: hp scaled by (sx,sy); if regression given: a = mv/(mv+0.1); out = a*hp + (1-a)*reg*reg_scale
+__global__ void k_fused_blend(const float* __restrict__ hp, const float* __restrict__ mv, const float* __restrict__ reg,
+                              float* __restrict__ out, int BK, float sx, float sy, float reg_scale) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= BK) return;
+    const float hx = hp[2 * i] * sx, hy = hp[2 * i + 1] * sy;
+    if (reg) {
+        const float a = mv[i] / (mv[i] + 0.1f);
+        out[2 * i] = a * hx + (1.f - a) * (reg[2 * i] * reg_scale);
+        out[2 * i + 1] = a * hy + (1.f - a) * (reg[2 * i + 1] * reg_scale);
+    } else {
+        out[2 * i] = hx;
+        out[2 * i + 1] = hy;
+    }
+}
+extern "C" int pk_fused_blend(const float* hp, const float* maxvals, const float* regression, float* out, int BK, float sx,
+                              float sy, float reg_scale, void* stream) {
+    PK_REQUIRE(hp && out && BK > 0 && (!regression || maxvals), "pk_fused_blend: bad argument");
+    hipLaunchKernelGGL(k_fused_blend, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, hp, maxvals, regression, out, BK,
+                       sx, sy, reg_scale);
+    return pk_launch_status("pk_fused_blend");
+}
+
+__global__ void k_affine_coords(const float* __restrict__ c, const float* __restrict__ center, const float* __restrict__ scale,
+                                float* __restrict__ out, int B, int K, float mx, float my, const float* __restrict__ mvals,
+                                float thr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * K) return;
+    const int b = i / K;
+    const float keep = mvals ? (mvals[i] > thr ? 1.f : 0.f) : 1.f;
+    out[2 * i] = (c[2 * i] * keep) * (scale[2 * b] * mx) + center[2 * b] - scale[2 * b] * 0.5f;
+    out[2 * i + 1] = (c[2 * i + 1] * keep) * (scale[2 * b + 1] * my) + center[2 * b + 1] - scale[2 * b + 1] * 0.5f;
+}
+extern "C" int pk_affine_coords(const float* coords, const float* center, const float* scale, float* out, int B, int K,
+                                float mul_x, float mul_y, const float* mask_maxvals, float threshold, void* stream) {
+    PK_REQUIRE(coords && center && scale && out && B > 0 && K > 0, "pk_affine_coords: bad argument");
+    hipLaunchKernelGGL(k_affine_coords, dim3((B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, coords, center, scale, out, B,
+                       K, mul_x, mul_y, mask_maxvals, threshold);
+    return pk_launch_status("pk_affine_coords");
+}
+
+// ================================================================================================ D4
+__global__ void __launch_bounds__(256) k_flip_merge(const float* __restrict__ a, const float* __restrict__ bf,
+                                                    const int32_t* __restrict__ partner, float* __restrict__ out, int K, int H,
+                                                    int W) {
+    const int map = blockIdx.x, b = map / K, k = map - b * K;
+    const float* pa = a + (size_t)map * H * W;
+    const float* pb = bf + ((size_t)b * K + partner[k]) * H * W;
+    float* po = out + (size_t)map * H * W;
+    for (int i = threadIdx.x; i < H * W; i += blockDim.x) {
+        const int y = i / W, x = i - y * W;
+        po[i] = (pa[i] + pb[y * W + (W - 1 - x)]) / 2.f;
+    }
+}
+extern "C" int pk_flip_merge(const float* a, const float* b_flipped, const int32_t* partner, float* out, int B, int K, int H,
+                             int W, void* stream) {
+    PK_REQUIRE(a && b_flipped && partner && out && B > 0 && K > 0 && H > 0 && W > 0, "pk_flip_merge: bad argument");
+    hipLaunchKernelGGL(k_flip_merge, dim3(B * K), dim3(256), 0, (hipStream_t)stream, a, b_flipped, partner, out, K, H, W);
+    return pk_launch_status("pk_flip_merge");
+}

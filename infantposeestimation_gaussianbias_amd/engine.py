@@ -1,0 +1,287 @@
+"""Training engine (S1): flat parameter storage, fused AdamW, per-iteration LR schedule, data-parallel gradient exchange.
+
+MI355X-first layout: all parameters live in ONE fp32 buffer, all gradients in another (each `param.data` / `param.grad`
+is a view), so
+  * the optimiser is one HIP launch over the whole model (pk_adamw_step) instead of ~820 per-tensor updates,
+  * the gradient all-reduce runs on a few large contiguous slices (RCCL over xGMI is per-link bound: few, big messages),
+    issued from autograd hooks while backward is still producing earlier layers' gradients,
+  * averaging over ranks is folded into the optimiser kernel (grad_scale = 1/world).
+Semantics follow train.py:55-128: AdamW(lr 5e-4, betas (.9,.999), wd .01 on the "decay" group), parameters whose name
+contains 'bias' / 'bn' / 'norm' are not decayed; parameters that never receive a gradient (41 tensors for
+HRFormer-small) are left untouched exactly as torch.optim.AdamW skips `grad is None`.
+"""
+import math
+import os
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from . import hipops
+
+
+def is_no_decay(name: str) -> bool:
+    return "bias" in name or "bn" in name or "norm" in name          # train.py:66
+
+
+def lr_factor(it: int, iters_per_epoch: int, cfg_train) -> float:
+    """LambdaLR factor, stepped per iteration: linear warm-up over warmup_epochs, then x gamma at each milestone epoch."""
+    warm = cfg_train.warmup_epochs * iters_per_epoch
+    if it < warm:
+        r = cfg_train.warmup_lr / cfg_train.lr
+        return r + (1 - r) * it / warm
+    f = 1.0
+    for m in cfg_train.lr_milestones:
+        if it >= m * iters_per_epoch:
+            f *= cfg_train.lr_gamma
+    return f
+
+
+class FlatAdamW:
+    """Owns the flat buffers of `model` and applies the fused optimiser step."""
+
+    ALIGN = 4            # elements: every tensor starts 16-byte aligned inside the flat buffers
+
+    def __init__(self, model: torch.nn.Module, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+        self.model = model
+        named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+        if not named:
+            raise ValueError("model has no trainable parameters")
+        dev = named[0][1].device
+        self.names = [n for n, _ in named]
+        self.params = [p for _, p in named]
+        self.offsets, off = [], 0
+        for p in self.params:
+            self.offsets.append(off)
+            off += -(-p.numel() // self.ALIGN) * self.ALIGN
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.exp_avg_sq = torch.zeros(off, dtype=torch.float32, device=dev)
+        flags = torch.zeros(off, dtype=torch.uint8)
+        for n, p, o in zip(self.names, self.params, self.offsets):
+            self.flat[o:o + p.numel()].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + p.numel()].view_as(p)
+            flags[o:o + p.numel()] = 2 | (0 if is_no_decay(n) else 1)
+        self.flags = flags.to(dev)
+        self.active = [True] * len(self.params)
+        self._grads_installed = False
+        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
+        self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.step_count = 0
+
+    # -- gradient storage ---------------------------------------------------------------------------------
+    def grad_view(self, i):
+        p, o = self.params[i], self.offsets[i]
+        return self.grad[o:o + p.numel()].view_as(p)
+
+    def install_grad_views(self):
+        """Adopt the gradients autograd produced on the first backward: parameters still without a gradient are the
+        structurally unused ones -> marked inactive (flag bit1 cleared) so the optimiser never touches them."""
+        inactive = []
+        for i, p in enumerate(self.params):
+            v = self.grad_view(i)
+            if p.grad is None:
+                self.active[i] = False
+                inactive.append(i)
+                v.zero_()
+            else:
+                v.copy_(p.grad)
+            p.grad = v
+        if inactive:
+            fl = self.flags.cpu()
+            for i in inactive:
+                o, n = self.offsets[i], self.params[i].numel()
+                fl[o:o + n] &= 0xFD
+            self.flags.copy_(fl)
+        self._grads_installed = True
+
+    def zero_grad(self):
+        if self._grads_installed:
+            self.grad.zero_()
+        else:
+            for p in self.params:
+                p.grad = None
+
+    # -- update ------------------------------------------------------------------------------------------------
+    def set_lr(self, lr: float):
+        self.lr = lr
+        self.lr_dev.fill_(lr)
+
+    def step(self, grad_scale: float = 1.0):
+        if not self._grads_installed:
+            self.install_grad_views()
+        self.step_count += 1
+        self.step_dev.add_(1)
+        hipops.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.flags, None, self.lr_dev, self.step_dev,
+                          self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)
+
+    # -- checkpoint format of the reference (train.py:351-357): per-parameter state keyed by index ---------------
+    def state_dict(self):
+        decay = [i for i, n in enumerate(self.names) if not is_no_decay(n)]
+        nodecay = [i for i, n in enumerate(self.names) if is_no_decay(n)]
+        order = decay + nodecay
+        remap = {old: new for new, old in enumerate(order)}
+        state = {}
+        for i, p in enumerate(self.params):
+            if not self.active[i] or self.step_count == 0:
+                continue
+            o, n = self.offsets[i], p.numel()
+            state[remap[i]] = {"step": torch.tensor(float(self.step_count)),
+                               "exp_avg": self.exp_avg[o:o + n].view_as(p).clone(),
+                               "exp_avg_sq": self.exp_avg_sq[o:o + n].view_as(p).clone()}
+        common = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "amsgrad": False, "maximize": False,
+                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "initial_lr": self.lr}
+        groups = [dict(common, weight_decay=self.weight_decay, params=[remap[i] for i in decay]),
+                  dict(common, weight_decay=0.0, params=[remap[i] for i in nodecay])]
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        decay = [i for i, n in enumerate(self.names) if not is_no_decay(n)]
+        nodecay = [i for i, n in enumerate(self.names) if is_no_decay(n)]
+        order = decay + nodecay
+        steps = 0
+        for new, old in enumerate(order):
+            st = sd["state"].get(new)
+            if st is None:
+                continue
+            o, n = self.offsets[old], self.params[old].numel()
+            self.exp_avg[o:o + n].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps = max(steps, int(float(st["step"])))
+        self.step_count = steps
+        self.step_dev.fill_(steps)
+        if sd.get("param_groups"):
+            self.set_lr(float(sd["param_groups"][0]["lr"]))
+
+
+class WarmupMultiStepLR:
+    """Per-iteration schedule of train.py:100-128 with LambdaLR's state_dict fields the reference checkpoints carry."""
+
+    def __init__(self, optimizer: FlatAdamW, cfg_train, iters_per_epoch: int):
+        self.opt, self.cfg, self.ipe = optimizer, cfg_train, iters_per_epoch
+        self.base_lr = cfg_train.lr
+        self.last_epoch = 0
+        optimizer.set_lr(self.base_lr * lr_factor(0, iters_per_epoch, cfg_train))
+
+    def step(self):
+        self.last_epoch += 1
+        self.opt.set_lr(self.base_lr * lr_factor(self.last_epoch, self.ipe, self.cfg))
+
+    def get_last_lr(self):
+        return [self.opt.lr, self.opt.lr]
+
+    def state_dict(self):
+        return {"base_lrs": [self.base_lr, self.base_lr], "last_epoch": self.last_epoch, "_step_count": self.last_epoch + 1,
+                "_last_lr": self.get_last_lr(), "lr_lambdas": [None]}
+
+    def load_state_dict(self, sd):
+        self.last_epoch = int(sd["last_epoch"])
+        self.opt.set_lr(self.base_lr * lr_factor(self.last_epoch, self.ipe, self.cfg))
+
+
+class GradientExchange:
+    """Data-parallel gradient sum over ranks on the flat gradient buffer (RCCL `nccl` backend on GPUs, gloo on CPU).
+
+    Buckets are contiguous slices of the flat buffer, built from the END (backward produces the last layers first).
+    Each bucket's all-reduce is launched asynchronously from a post-accumulate hook as soon as all of its *active*
+    parameters have their gradient, overlapping communication with the rest of backward; `finish()` waits for all."""
+
+    def __init__(self, opt: FlatAdamW, bucket_mb: float = 16.0, group=None):
+        self.opt, self.group = opt, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
+        self.buckets: List[Dict] = []
+        self._hooks = []
+        self._pending = []
+        self._armed = False
+
+    def broadcast_initial_state(self):
+        if self.world == 1:
+            return
+        dist.broadcast(self.opt.flat, 0, group=self.group)
+        for b in self.opt.model.buffers():
+            dist.broadcast(b, 0, group=self.group)
+
+    def _build(self):
+        opt = self.opt
+        hi, cur, members = opt.numel, opt.numel, []
+        plan = []
+        for i in reversed(range(len(opt.params))):
+            members.append(i)
+            cur = opt.offsets[i]
+            if hi - cur >= self.bucket_elems or i == 0:
+                plan.append((cur, hi, members))
+                hi, members = cur, []
+        self.buckets = [{"lo": lo, "hi": hi_, "need": sum(1 for i in m if opt.active[i]), "got": 0} for lo, hi_, m in plan]
+        owner = {}
+        for b, (_, _, m) in enumerate(plan):
+            for i in m:
+                owner[i] = b
+        for i, p in enumerate(opt.params):
+            if opt.active[i]:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[i])))
+        self._armed = True
+
+    def _make_hook(self, b):
+        def hook(_param):
+            bk = self.buckets[b]
+            bk["got"] += 1
+            if bk["got"] == bk["need"]:
+                self._launch(bk)
+        return hook
+
+    def _launch(self, bk):
+        bk["got"] = -1     # launched
+        self._pending.append(dist.all_reduce(self.opt.grad[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Call after backward: flush buckets that did not fire (first step, or only inactive members), wait for all."""
+        if self.world == 1:
+            return
+        if not self.opt._grads_installed:
+            self.opt.install_grad_views()
+        if not self._armed:
+            self._build()
+            for bk in self.buckets:        # first step ran without hooks: reduce everything now
+                self._launch(bk)
+        else:
+            for bk in self.buckets:
+                if bk["got"] != -1:
+                    self._launch(bk)
+        for w in self._pending:
+            w.wait()
+        self._pending.clear()
+        for bk in self.buckets:
+            bk["got"] = 0
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+
+class Trainer:
+    """One optimisation step of train.py::train_one_epoch (:169-187) without its per-step host syncs."""
+
+    def __init__(self, model, cfg, iters_per_epoch: int, bucket_mb: float = 16.0):
+        self.model, self.cfg = model, cfg
+        t = cfg.train
+        if t.optimizer != "AdamW":
+            raise ValueError(f"Unknown optimizer: {t.optimizer}")   # the fused kernel implements the reference default only
+        self.opt = FlatAdamW(model, t.lr, tuple(t.betas), 1e-8, t.weight_decay)
+        self.sched = WarmupMultiStepLR(self.opt, t, iters_per_epoch)
+        self.comm = GradientExchange(self.opt, bucket_mb)
+        self.comm.broadcast_initial_state()
+
+    def step(self, batch):
+        self.model.train()
+        self.opt.zero_grad()
+        out = self.model(batch["img"], batch["target"], batch["target_weight"], gt_keypoints=batch.get("keypoints"),
+                         input_size=self.cfg.data.input_size)
+        out["loss"].backward()
+        self.comm.finish()
+        self.opt.step(self.comm.grad_scale)
+        self.sched.step()
+        return out

@@ -1,0 +1,206 @@
+"""Host-side wrappers over the C-ABI: argument checking, output allocation (torch owns device memory),
+and `torch.autograd.Function`s for the differentiable ops.  Every function here launches HIP kernels from
+libposekernels.so on the current torch stream; none has a PyTorch fallback.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call, stream_ptr
+
+F32, I32 = torch.float32, torch.int32
+
+
+def _chk(t, dtype=F32, name="tensor"):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise _lib.PoseKernelError(f"{name}: expected a CUDA(HIP) tensor; the hot path has no CPU implementation")
+    if t.dtype != dtype:
+        raise _lib.PoseKernelError(f"{name}: expected {dtype}, got {t.dtype}")
+    return t.contiguous()
+
+
+# ------------------------------------------------------------------------------------------------ T1 / T2
+_LUT_CACHE = {}
+
+
+def _patch_lut(sigma: float, device):
+    """Host-built LUT of the reference's float32 patch (datasets/coco_dataset.py:227-233), indexed by d²."""
+    key = (float(sigma), str(device))
+    if key not in _LUT_CACHE:
+        size = 2 * (sigma * 3) + 1
+        ax = np.arange(0, size, 1, np.float32)
+        c = size // 2
+        g = np.exp(-((ax[None, :] - c) ** 2 + (ax[:, None] - c) ** 2) / (2 * sigma ** 2))   # same float32 expression
+        n, ci = g.shape[0], int(c)
+        far = max(ci, n - 1 - ci)
+        lut = np.zeros(2 * far * far + 1, np.float32)
+        for j in range(n):
+            for i in range(n):
+                lut[(i - ci) ** 2 + (j - ci) ** 2] = g[j, i]
+        _LUT_CACHE[key] = (torch.from_numpy(lut).to(device), n, ci)
+    return _LUT_CACHE[key]
+
+
+def gaussian_target(keypoints, visible, input_size, heatmap_size, sigma):
+    """(B,K,2),(B,K) -> target (B,K,Hh,Wh), weight (B,K,1). Sizes are (W,H) as in the reference config."""
+    kp, vis = _chk(keypoints, name="keypoints"), _chk(visible, name="visible")
+    B, K = vis.shape
+    wh, hh = int(heatmap_size[0]), int(heatmap_size[1])
+    lut, n, c = _patch_lut(float(sigma), kp.device)
+    target = torch.empty(B, K, hh, wh, dtype=F32, device=kp.device)
+    weight = torch.empty(B, K, 1, dtype=F32, device=kp.device)
+    call("pk_gaussian_target", kp, vis, lut, lut.numel(), target, weight, B, K, hh, wh,
+         float(input_size[0]) / float(heatmap_size[0]), float(input_size[1]) / float(heatmap_size[1]), float(sigma) * 3, n, c,
+         stream_ptr())
+    return target, weight
+
+
+def dense_target(keypoints, visible, input_size_hw, heatmap_size_hw, sigma):
+    kp, vis = _chk(keypoints, name="keypoints"), _chk(visible, name="visible")
+    B, K = vis.shape
+    hh, hw = int(heatmap_size_hw[0]), int(heatmap_size_hw[1])
+    hm = torch.empty(B, K, hh, hw, dtype=F32, device=kp.device)
+    w = torch.empty(B, K, dtype=F32, device=kp.device)
+    call("pk_dense_target", kp, vis, hm, w, B, K, hh, hw, float(np.float32(hw / input_size_hw[1])),
+         float(np.float32(hh / input_size_hw[0])), float(sigma), stream_ptr())
+    return hm, w
+
+
+# ------------------------------------------------------------------------------------------------ decoders
+def argmax_decode(heatmaps, mode=0):
+    """-> index (B,K) int32, maxval (B,K), coords (B,K,2). mode 0 plain / 1 quarter-shift / 2 Taylor."""
+    hm = _chk(heatmaps, name="heatmaps")
+    B, K, H, W = hm.shape
+    idx = torch.empty(B, K, dtype=I32, device=hm.device)
+    mv = torch.empty(B, K, dtype=F32, device=hm.device)
+    co = torch.empty(B, K, 2, dtype=F32, device=hm.device)
+    call("pk_argmax_decode", hm, idx, mv, co, B * K, H, W, int(mode), stream_ptr())
+    return idx, mv, co
+
+
+def softargmax_refine_decode(heatmaps, offsets, alpha_param, fusion_weight_param, radius=2):
+    hm = _chk(heatmaps, name="heatmaps")
+    B, K, H, W = hm.shape
+    off = None if offsets is None else _chk(offsets, name="offsets")
+    co = torch.empty(B, K, 2, dtype=F32, device=hm.device)
+    sc = torch.empty(B, K, dtype=F32, device=hm.device)
+    call("pk_softargmax_refine_decode", hm, off, _chk(alpha_param.reshape(1)), None if off is None else _chk(fusion_weight_param.reshape(1)),
+         co, sc, B * K, H, W, int(radius), stream_ptr())
+    return co, sc
+
+
+def window_refine(heatmaps, coords, window=5):
+    hm, c = _chk(heatmaps), _chk(coords)
+    B, K, H, W = hm.shape
+    out = torch.empty_like(c)
+    call("pk_window_refine", hm, c, out, B * K, H, W, int(window), stream_ptr())
+    return out
+
+
+def fused_blend(hp, maxvals, regression, sx, sy, reg_scale):
+    hp = _chk(hp)
+    out = torch.empty_like(hp)
+    call("pk_fused_blend", hp, None if maxvals is None else _chk(maxvals), None if regression is None else _chk(regression), out,
+         hp.shape[0] * hp.shape[1], float(sx), float(sy), float(reg_scale), stream_ptr())
+    return out
+
+
+def affine_coords(coords, center, scale, mul_x, mul_y, mask_maxvals=None, threshold=0.0):
+    c = _chk(coords)
+    B, K = c.shape[:2]
+    out = torch.empty_like(c)
+    call("pk_affine_coords", c, _chk(center), _chk(scale), out, B, K, float(mul_x), float(mul_y),
+         None if mask_maxvals is None else _chk(mask_maxvals), float(threshold), stream_ptr())
+    return out
+
+
+def flip_merge(hm, hm_from_flipped, partner):
+    a, b = _chk(hm), _chk(hm_from_flipped)
+    B, K, H, W = a.shape
+    out = torch.empty_like(a)
+    call("pk_flip_merge", a, b, _chk(partner, I32), out, B, K, H, W, stream_ptr())
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ losses
+def loss_ws_floats(B, K):
+    return B * K * 24 + B * 16 * 4 + 16
+
+
+class _FusionLoss(torch.autograd.Function):
+    """L1/L2 forward + hand-derived backward (fusion_head.py:745-806). Returns the 7 loss values as one tensor."""
+
+    @staticmethod
+    def forward(ctx, hm, off, var, target, weight, gt, in_w, in_h, sigma_t, lambdas):
+        hm, off, var = _chk(hm, name="heatmaps"), _chk(off, name="offsets"), _chk(var, name="variances")
+        target, weight, gt = _chk(target), _chk(weight), _chk(gt)
+        B, K, H, W = hm.shape
+        if off.shape != (B, K, 2, H, W) or var.shape != hm.shape or target.shape != hm.shape or weight.numel() != B * K or gt.shape != (B, K, 2):
+            raise _lib.PoseKernelError("fusion loss: inconsistent shapes")
+        ws = torch.empty(loss_ws_floats(B, K), dtype=F32, device=hm.device)
+        losses = torch.empty(7, dtype=F32, device=hm.device)
+        call("pk_fusion_loss_fwd", hm, off, var, target, weight, gt, ws, losses, B, K, H, W, float(in_w), float(in_h), float(sigma_t),
+             lambdas, stream_ptr())
+        ctx.save_for_backward(hm, off, var, target, weight, ws, lambdas)
+        ctx.sigma_t = float(sigma_t)
+        return losses
+
+    @staticmethod
+    def backward(ctx, g):
+        hm, off, var, target, weight, ws, lambdas = ctx.saved_tensors
+        B, K, H, W = hm.shape
+        # d(sum_i g_i * loss_i): entries 0..5 are the weighted terms and entry 6 their sum, so the per-term
+        # multipliers are lambdas*(g[:6]+g[6]); the kernel takes them as "lambdas" with grad_total = 1.
+        eff = (lambdas * (g[:6] + g[6])).contiguous()
+        dhm, doff, dvar = torch.empty_like(hm), torch.empty_like(off), torch.empty_like(var)
+        call("pk_fusion_loss_bwd", hm, off, var, target, weight, ws, None, dhm, doff, dvar, B, K, H, W, ctx.sigma_t, eff, stream_ptr())
+        return dhm, doff, dvar, None, None, None, None, None, None, None
+
+
+def fusion_loss(hm, off, var, target, weight, gt, input_size, sigma_t, lambdas_dev):
+    return _FusionLoss.apply(hm, off, var, target, weight, gt, float(input_size[0]), float(input_size[1]), sigma_t, lambdas_dev)
+
+
+class _PixelLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target, weight, kind):
+        pred, target = _chk(pred), _chk(target)
+        B, K = pred.shape[:2]
+        HW = pred.numel() // (B * K)
+        w = None if weight is None else _chk(weight)
+        partial = torch.empty(1024, dtype=F32, device=pred.device)
+        loss = torch.empty(1, dtype=F32, device=pred.device)
+        call("pk_pixel_loss_fwd", pred, target, w, partial, loss, B, K, HW, kind, stream_ptr())
+        ctx.save_for_backward(pred, target, w if w is not None else pred.new_empty(0))
+        ctx.kind, ctx.has_w = kind, w is not None
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, target, w = ctx.saved_tensors
+        B, K = pred.shape[:2]
+        dp = torch.empty_like(pred)
+        call("pk_pixel_loss_bwd", pred, target, w if ctx.has_w else None, _chk(g.reshape(1).float()), dp, B, K, pred.numel() // (B * K), ctx.kind,
+             stream_ptr())
+        return dp, None, None, None
+
+
+def pixel_loss(pred, target, weight, kind):
+    return _PixelLoss.apply(pred, target, weight, int(kind))
+
+
+def spatial_stats(hm):
+    hm = _chk(hm)
+    B, K, H, W = hm.shape
+    mean = torch.empty(B, K, 2, dtype=F32, device=hm.device)
+    var = torch.empty(B, K, 2, dtype=F32, device=hm.device)
+    call("pk_spatial_stats", hm, mean, var, B * K, H, W, stream_ptr())
+    return mean, var
+
+
+# ------------------------------------------------------------------------------------------------ optimiser
+def adamw_step(param, grad, exp_avg, exp_avg_sq, flags, param_bf16, lr_dev, step_dev, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    call("pk_adamw_step", param, grad, exp_avg, exp_avg_sq, flags, param_bf16, param.numel(), lr_dev, step_dev, float(beta1), float(beta2),
+         float(eps), float(weight_decay), float(grad_scale), stream_ptr())

@@ -1,0 +1,143 @@
+"""Fusion head: heatmap + offset-regression + variance branches, its decoder and its loss
+(drop-in for the reference's models/fusion_head.py).
+
+Everything numerical runs in libposekernels: `decode` is one kernel per batch (no Python B x K loop, no .item()),
+`FusionPoseLoss` is a fused forward (3 launches) + a hand-derived backward (1 launch).
+"""
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import hipops, nnops
+from ._blocks import conv
+
+
+class SoftArgmax2D(nn.Module):
+    """Soft-argmax coordinates + raw-max scores (fusion_head.py:24-71). beta must be 1 (the only value the reference uses)."""
+
+    def __init__(self, beta: float = 1.0):
+        super().__init__()
+        if beta != 1.0:
+            raise ValueError("SoftArgmax2D: only beta=1.0 is supported")
+        self.beta = beta
+
+    def forward(self, heatmaps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        one = torch.full((1,), 40.0, device=heatmaps.device)          # sigmoid(40) == 1: pure global soft-argmax
+        return hipops.softargmax_refine_decode(heatmaps.float(), None, one, None, radius=0)
+
+
+class SubPixelRefinement(nn.Module):
+    """Holds `alpha` (fusion_head.py:131-172); the blend itself happens inside the decode kernel."""
+
+    def __init__(self, beta: float = 1.0, local_radius: int = 2, fusion_alpha: float = 0.5):
+        super().__init__()
+        self.local_radius = local_radius
+        self.alpha = nn.Parameter(torch.tensor(fusion_alpha))
+
+    def forward(self, heatmaps):
+        return hipops.softargmax_refine_decode(heatmaps.float(), None, self.alpha.detach(), None, self.local_radius)
+
+
+def _branch(cin, hidden, cout):
+    """[conv3x3, BN, ReLU, conv1x1+bias] with the reference's Sequential indices 0,1,(2),3."""
+    seq = nn.ModuleDict({"0": conv(cin, hidden, 3), "1": nn.BatchNorm2d(hidden), "3": nn.Conv2d(hidden, cout, 1)})
+    return seq
+
+
+class HeatmapRegressionHead(nn.Module):
+    def __init__(self, in_channels: int, num_keypoints: int = 17, hidden_dim: int = 256, use_subpixel_refinement: bool = True):
+        super().__init__()
+        self.in_channels, self.num_keypoints, self.use_subpixel_refinement = in_channels, num_keypoints, use_subpixel_refinement
+        self.shared_layers = nn.ModuleDict({"0": conv(in_channels, hidden_dim, 3), "1": nn.BatchNorm2d(hidden_dim),
+                                            "3": conv(hidden_dim, hidden_dim, 3), "4": nn.BatchNorm2d(hidden_dim)})
+        self.heatmap_branch = _branch(hidden_dim, hidden_dim, num_keypoints)
+        self.offset_branch = _branch(hidden_dim, hidden_dim, num_keypoints * 2)
+        self.variance_branch = _branch(hidden_dim, hidden_dim // 2, num_keypoints)
+        if use_subpixel_refinement:
+            self.subpixel_refine = SubPixelRefinement(1.0, 2, 0.5)
+        self.fusion_weight = nn.Parameter(torch.tensor(0.5))
+        for m in self.modules():                                    # fusion_head.py:268-276
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+
+    def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        tr = self.training
+        if x.dtype != nnops.ACT_DTYPE:
+            x = nnops.to_features(x)
+        s = self.shared_layers
+        f = nnops.conv_bn_act(x, s["0"], s["1"], True, None, tr)
+        f = nnops.conv_bn_act(f, s["3"], s["4"], True, None, tr)
+
+        def run(br, softplus=False):
+            t = nnops.conv_bn_act(f, br["0"], br["1"], True, None, tr)
+            return nnops.head_out(t, br["3"], softplus)
+
+        heatmaps = run(self.heatmap_branch)
+        offsets = run(self.offset_branch)
+        B, _, H, W = offsets.shape
+        return {"heatmaps": heatmaps, "offsets": offsets.view(B, self.num_keypoints, 2, H, W),
+                "variances": run(self.variance_branch, True), "fusion_weight": torch.sigmoid(self.fusion_weight)}
+
+    @torch.no_grad()
+    def decode(self, outputs: Dict[str, torch.Tensor], apply_offset: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> keypoints (B,K,2) in heatmap pixels, scores (B,K) (fusion_head.py:309-365)."""
+        hm = outputs["heatmaps"].float()
+        if self.use_subpixel_refinement:
+            alpha, radius = self.subpixel_refine.alpha.detach(), self.subpixel_refine.local_radius
+        else:
+            alpha, radius = torch.full((1,), 40.0, device=hm.device), 0
+        if not apply_offset:
+            return hipops.softargmax_refine_decode(hm, None, alpha, None, radius)
+        fw = outputs["fusion_weight"].detach().float().reshape(1)
+        raw = torch.log(fw / (1 - fw))                               # kernel applies sigmoid to the raw parameter
+        return hipops.softargmax_refine_decode(hm, outputs["offsets"].float(), alpha, raw, radius)
+
+
+class GaussianDistributionConstraint(nn.Module):
+    """Kept for API parity (fusion_head.py:372-575); its three terms are computed inside the fused loss kernel."""
+    SKELETON = [(0, 1), (0, 2), (1, 3), (2, 4), (5, 6), (5, 7), (7, 9), (6, 8), (8, 10), (5, 11), (6, 12), (11, 12),
+                (11, 13), (13, 15), (12, 14), (14, 16)]
+
+    def __init__(self, target_sigma: float = 2.0, overlap_threshold: float = 0.5):
+        super().__init__()
+        if overlap_threshold != 0.5:
+            raise ValueError("overlap_threshold is fixed at 0.5 in the fused kernel")
+        self.target_sigma, self.overlap_threshold = target_sigma, overlap_threshold
+
+
+class FusionPoseLoss(nn.Module):
+    NAMES = ("heatmap_loss", "offset_loss", "peak_loss", "variance_loss", "overlap_loss", "shape_loss", "total_loss")
+
+    def __init__(self, heatmap_weight: float = 1.0, offset_weight: float = 1.0, peak_weight: float = 0.5,
+                 variance_weight: float = 0.1, overlap_weight: float = 0.05, shape_weight: float = 0.05,
+                 target_sigma: float = 2.0, use_target_weight: bool = True):
+        super().__init__()
+        if not use_target_weight:
+            raise ValueError("FusionPoseLoss: use_target_weight=False is not implemented in the fused kernel")
+        self.heatmap_weight, self.offset_weight, self.peak_weight = heatmap_weight, offset_weight, peak_weight
+        self.variance_weight, self.overlap_weight, self.shape_weight = variance_weight, overlap_weight, shape_weight
+        self.use_target_weight = use_target_weight
+        self.gaussian_constraint = GaussianDistributionConstraint(target_sigma)
+        self.soft_argmax = SoftArgmax2D()
+        self.register_buffer("_lambdas", torch.tensor([heatmap_weight, offset_weight, peak_weight, variance_weight,
+                                                       overlap_weight, shape_weight], dtype=torch.float32), persistent=False)
+
+    def forward(self, outputs, target_heatmaps, target_weight, gt_keypoints, input_size=(192, 256), heatmap_size=(48, 64)):
+        vals = hipops.fusion_loss(outputs["heatmaps"], outputs["offsets"], outputs["variances"], target_heatmaps.float(),
+                                  target_weight.float(), gt_keypoints.float(), input_size, self.gaussian_constraint.target_sigma,
+                                  self._lambdas)
+        return {n: vals[i] for i, n in enumerate(self.NAMES)}
+
+
+def build_fusion_head(in_channels: int, num_keypoints: int = 17, hidden_dim: int = 256) -> HeatmapRegressionHead:
+    return HeatmapRegressionHead(in_channels, num_keypoints, hidden_dim, True)
+
+
+def build_fusion_loss(target_sigma: float = 2.0, heatmap_weight: float = 1.0, offset_weight: float = 1.0,
+                      variance_weight: float = 0.1) -> FusionPoseLoss:
+    return FusionPoseLoss(heatmap_weight=heatmap_weight, offset_weight=offset_weight, variance_weight=variance_weight,
+                          target_sigma=target_sigma)

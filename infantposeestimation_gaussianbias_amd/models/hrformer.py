@@ -1,0 +1,145 @@
+"""HRFormer backbone (drop-in for the reference's models/hrformer.py: same constructors, same state_dict keys).
+
+Input (B,3,H,W) fp32 NCHW; output the branch-0 feature map (B,C0,H/4,W/4) as a channels_last bf16 tensor
+(NHWC bytes).  Stage structure follows hrformer.py:505-616: stem -> 2 bottlenecks -> stage2 (1 module, 2 branches)
+-> stage3 (4 modules, 3 branches) -> stage4 (2 modules, 4 branches), 2 window-attention blocks per branch,
+exchange unit after every module; only output 0 of the last module is returned (hrformer.py:776).
+"""
+from typing import Sequence
+
+import torch
+import torch.nn as nn
+
+from .. import nnops
+from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, make_transition, run_transition
+
+
+class WindowAttentionParams(nn.Module):
+    """qkv/proj + relative-position table (169, heads) + the (49,49) index buffer (hrformer.py:147-170)."""
+
+    def __init__(self, dim, heads, ws=7):
+        super().__init__()
+        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 2, heads))
+        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+        ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+        ys, xs = ys.reshape(-1), xs.reshape(-1)
+        self.register_buffer("relative_position_index",
+                             (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1))
+        self.qkv = nn.Linear(dim, dim * 3)
+        self.proj = nn.Linear(dim, dim)
+
+
+class MlpParams(nn.Module):
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class HRFormerBlock(nn.Module):
+    def __init__(self, dim, heads, mlp_ratio=4.0, drop_path=0.0):
+        super().__init__()
+        self.dim, self.heads, self.drop_prob = dim, heads, float(drop_path)
+        self.norm1 = nn.LayerNorm(dim)
+        self.attn = WindowAttentionParams(dim, heads)
+        self.norm2 = nn.LayerNorm(dim)
+        self.mlp = MlpParams(dim, int(dim * mlp_ratio))
+
+
+class HRFormerModule(nn.Module):
+    def __init__(self, channels, heads, blocks_per_branch, mlp_ratios, drop_path):
+        super().__init__()
+        self.branches = nn.ModuleList(
+            nn.ModuleList(HRFormerBlock(c, h, r, drop_path) for _ in range(nb))
+            for c, h, nb, r in zip(channels, heads, blocks_per_branch, mlp_ratios))
+        if len(channels) > 1:
+            self.fuse_layers = make_fuse_layers(channels)
+
+    def n_draws(self):
+        return 2 * sum(len(b) for b in self.branches)
+
+    def forward(self, xs, scales=None):
+        """scales: (n_draws, B) DropPath multipliers for this module (two per block, branch-major), or None."""
+        ys, d = [], 0
+        for b, blocks in enumerate(self.branches):
+            t = xs[b]
+            for blk in blocks:
+                s1, s2 = (scales[d], scales[d + 1]) if scales is not None else (None, None)
+                d += 2
+                t = nnops.window_block(t, blk, blk.heads, s1, s2)
+            ys.append(t)
+        if len(ys) == 1:
+            return ys
+        return nnops.exchange(ys, self.fuse_layers, self.training)
+
+
+class HRFormer(nn.Module):
+    def __init__(self, in_channels: int = 3, drop_path_rate: float = 0.2, with_rpe: bool = True,
+                 stage1_num_modules: int = 1, stage1_num_branches: int = 1, stage1_num_blocks: Sequence[int] = (2,),
+                 stage1_num_channels: Sequence[int] = (64,),
+                 stage2_num_modules: int = 1, stage2_num_branches: int = 2, stage2_num_blocks=(2, 2),
+                 stage2_num_channels=(78, 156), stage2_num_heads=(2, 4), stage2_mlp_ratios=(4, 4), stage2_window_sizes=(7, 7),
+                 stage3_num_modules: int = 4, stage3_num_branches: int = 3, stage3_num_blocks=(2, 2, 2),
+                 stage3_num_channels=(78, 156, 312), stage3_num_heads=(2, 4, 8), stage3_mlp_ratios=(4, 4, 4),
+                 stage3_window_sizes=(7, 7, 7),
+                 stage4_num_modules: int = 2, stage4_num_branches: int = 4, stage4_num_blocks=(2, 2, 2, 2),
+                 stage4_num_channels=(78, 156, 312, 624), stage4_num_heads=(2, 4, 8, 16), stage4_mlp_ratios=(4, 4, 4, 4),
+                 stage4_window_sizes=(7, 7, 7, 7)):
+        super().__init__()
+        if not with_rpe:
+            raise ValueError("with_rpe=False is not supported by the fused window-attention kernels")
+        for ws in (*stage2_window_sizes, *stage3_window_sizes, *stage4_window_sizes):
+            if ws != 7:
+                raise ValueError("window size must be 7")
+        self.drop_path_rate = drop_path_rate
+        self.conv1, self.bn1 = conv(in_channels, 64, 3, 2), nn.BatchNorm2d(64)
+        self.conv2, self.bn2 = conv(64, 64, 3, 2), nn.BatchNorm2d(64)
+        planes = stage1_num_channels[0]
+        self.layer1 = nn.ModuleList(Residual(64 if i == 0 else planes * 4, planes, True, project=(i == 0 and 64 != planes * 4))
+                                    for i in range(stage1_num_blocks[0]))
+        pre = [planes * 4]
+        for s, (nm, ch, hd, nb, mr) in enumerate(((stage2_num_modules, stage2_num_channels, stage2_num_heads, stage2_num_blocks, stage2_mlp_ratios),
+                                                  (stage3_num_modules, stage3_num_channels, stage3_num_heads, stage3_num_blocks, stage3_mlp_ratios),
+                                                  (stage4_num_modules, stage4_num_channels, stage4_num_heads, stage4_num_blocks, stage4_mlp_ratios)), start=2):
+            setattr(self, f"transition{s - 1}", make_transition(pre, list(ch)))
+            setattr(self, f"stage{s}", nn.ModuleList(HRFormerModule(list(ch), list(hd), list(nb), list(mr), drop_path_rate) for _ in range(nm)))
+            pre = list(ch)
+        self.out_channels = stage4_num_channels[0]
+        init_backbone_weights(self)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        tr = self.training
+        x = nnops.to_features(x)
+        x = nnops.conv_bn_act(x, self.conv1, self.bn1, True, None, tr)
+        x = nnops.conv_bn_act(x, self.conv2, self.bn2, True, None, tr)
+        for blk in self.layer1:
+            x = blk(x)
+        ys = [x]
+        mods = [m for s in (2, 3, 4) for m in getattr(self, f"stage{s}")]
+        scales = None
+        if tr and self.drop_path_rate > 0:
+            scales = nnops.drop_scales(sum(m.n_draws() for m in mods), x.shape[0], self.drop_path_rate, x.device)
+        d = 0
+        for s in (2, 3, 4):
+            ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
+            for m in getattr(self, f"stage{s}"):
+                n = m.n_draws()
+                ys = m(ys, None if scales is None else scales[d:d + n])
+                d += n
+        return ys[0]
+
+
+def hrformer_base(pretrained: bool = False, **kwargs) -> HRFormer:
+    """HRFormer-Base: C=(78,156,312,624), heads (2,4,8,16) -> head_dim 39, drop_path 0.2 (hrformer.py:779-825)."""
+    kwargs.setdefault("drop_path_rate", 0.2)
+    return HRFormer(in_channels=3, with_rpe=True, **kwargs)
+
+
+def hrformer_small(pretrained: bool = False, **kwargs) -> HRFormer:
+    """HRFormer-Small: C=(32,64,128,256), heads (1,2,4,8), drop_path 0.1 (hrformer.py:828-846).
+    Unlike the reference (duplicate-kwarg TypeError), `drop_path_rate=` may be overridden here."""
+    kwargs.setdefault("drop_path_rate", 0.1)
+    return HRFormer(in_channels=3, with_rpe=True,
+                    stage2_num_channels=(32, 64), stage2_num_heads=(1, 2),
+                    stage3_num_channels=(32, 64, 128), stage3_num_heads=(1, 2, 4),
+                    stage4_num_channels=(32, 64, 128, 256), stage4_num_heads=(1, 2, 4, 8), **kwargs)

@@ -1,0 +1,72 @@
+"""HRNet backbone (drop-in for the reference's models/hrnet.py: `HRNet(base_channels)`, `hrnet_w32/w48`).
+
+Stem -> 4 bottlenecks -> stage2 (1 module) -> stage3 (4 modules) -> stage4 (3 modules), 4 BasicBlocks per branch per
+module, exchange unit after each module (hrnet.py:243-302); returns branch 0 only (hrnet.py:441).
+"""
+import torch
+import torch.nn as nn
+
+from .. import nnops
+from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, make_transition, run_transition
+
+
+class HighResolutionModule(nn.Module):
+    def __init__(self, channels, blocks_per_branch):
+        super().__init__()
+        self.branches = nn.ModuleList(nn.ModuleList(Residual(c, c, False) for _ in range(nb))
+                                      for c, nb in zip(channels, blocks_per_branch))
+        if len(channels) > 1:
+            self.fuse_layers = make_fuse_layers(channels)
+
+    def forward(self, xs):
+        ys = []
+        for b, blocks in enumerate(self.branches):
+            t = xs[b]
+            for blk in blocks:
+                t = blk(t)
+            ys.append(t)
+        return ys if len(ys) == 1 else nnops.exchange(ys, self.fuse_layers, self.training)
+
+
+class HRNet(nn.Module):
+    def __init__(self, in_channels: int = 3, base_channels: int = 32):
+        super().__init__()
+        c = self.base_channels = base_channels
+        self.conv1, self.bn1 = conv(in_channels, 64, 3, 2), nn.BatchNorm2d(64)
+        self.conv2, self.bn2 = conv(64, 64, 3, 2), nn.BatchNorm2d(64)
+        self.layer1 = nn.ModuleList(Residual(64 if i == 0 else 256, 64, True, project=(i == 0)) for i in range(4))
+        pre = [256]
+        for s, nm in ((2, 1), (3, 4), (4, 3)):
+            ch = [c * (2 ** i) for i in range(s)]
+            setattr(self, f"transition{s - 1}", make_transition(pre, ch))
+            setattr(self, f"stage{s}", nn.ModuleList(HighResolutionModule(ch, [4] * s) for _ in range(nm)))
+            pre = ch
+        self.out_channels = c
+        init_backbone_weights(self)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        tr = self.training
+        x = nnops.to_features(x)
+        x = nnops.conv_bn_act(x, self.conv1, self.bn1, True, None, tr)
+        x = nnops.conv_bn_act(x, self.conv2, self.bn2, True, None, tr)
+        for blk in self.layer1:
+            x = blk(x)
+        ys = [x]
+        for s in (2, 3, 4):
+            ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
+            for m in getattr(self, f"stage{s}"):
+                ys = m(ys)
+        return ys[0]
+
+
+def hrnet_w32(pretrained: bool = False) -> HRNet:
+    return HRNet(base_channels=32)
+
+
+def hrnet_w48(pretrained: bool = False) -> HRNet:
+    return HRNet(base_channels=48)
+
+
+def hrnet_w18(pretrained: bool = False) -> HRNet:
+    """BASELINE config 1 (`HRNet(base_channels=18)`); the reference has no named constructor for it."""
+    return HRNet(base_channels=18)

@@ -1,0 +1,105 @@
+"""PoseEstimator / build_model: the drop-in surface of the reference's models/pose_estimator.py."""
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from .. import hipops, nnops
+from .fusion_head import FusionPoseLoss, HeatmapRegressionHead, SoftArgmax2D
+from .hrformer import hrformer_base, hrformer_small
+from .hrnet import hrnet_w18, hrnet_w32, hrnet_w48
+
+_BACKBONES = {"hrnet_w32": (hrnet_w32, 32), "hrnet_w48": (hrnet_w48, 48), "hrnet_w18": (hrnet_w18, 18),
+              "hrformer_base": (hrformer_base, 78), "hrformer_small": (hrformer_small, 32)}
+
+
+class HeatmapHead(nn.Module):
+    """1x1 conv to K maps, init N(0, 0.001) (pose_estimator.py:22-99). Deconv stacks (never enabled by the
+    reference: num_deconv_layers=0 at its only call site) are not built."""
+
+    def __init__(self, in_channels: int, out_channels: int, num_deconv_layers: int = 0, num_deconv_filters=(256, 256, 256),
+                 num_deconv_kernels=(4, 4, 4)):
+        super().__init__()
+        if num_deconv_layers != 0:
+            raise ValueError("HeatmapHead: deconv layers are not supported (the reference never enables them)")
+        self.in_channels, self.out_channels, self.deconv = in_channels, out_channels, None
+        self.final_layer = nn.Conv2d(in_channels, out_channels, 1)
+        nn.init.normal_(self.final_layer.weight, std=0.001)
+        nn.init.zeros_(self.final_layer.bias)
+
+    def forward(self, x):
+        if x.dtype != nnops.ACT_DTYPE:
+            x = nnops.to_features(x)
+        return nnops.head_out(x, self.final_layer)
+
+
+class KeypointMSELoss(nn.Module):
+    def __init__(self, use_target_weight: bool = True):
+        super().__init__()
+        self.use_target_weight = use_target_weight
+
+    def forward(self, pred, target, target_weight=None):
+        w = target_weight.float() if (self.use_target_weight and target_weight is not None) else None
+        return hipops.pixel_loss(pred.float(), target.float(), w, 0)
+
+
+class PoseEstimator(nn.Module):
+    def __init__(self, backbone: str = "hrformer_base", num_keypoints: int = 17, pretrained: bool = True,
+                 head_type: str = "fusion", use_fusion_loss: bool = True):
+        super().__init__()
+        if backbone not in _BACKBONES:
+            raise ValueError(f"Unknown backbone: {backbone}")
+        ctor, in_channels = _BACKBONES[backbone]
+        self.head_type = head_type
+        self.use_fusion_loss = use_fusion_loss and head_type == "fusion"
+        self.backbone = ctor(pretrained=pretrained)
+        if head_type == "fusion":
+            self.head = HeatmapRegressionHead(in_channels, num_keypoints, 256, True)
+            self.loss_fn = FusionPoseLoss(1.0, 1.0, 0.5, 0.1, 0.05, 0.05, 2.0, True)
+        else:
+            self.head = HeatmapHead(in_channels, num_keypoints, 0)
+            self.loss_fn = KeypointMSELoss(True)
+        self.num_keypoints = num_keypoints
+        self.soft_argmax = SoftArgmax2D()
+
+    def forward(self, x, target=None, target_weight=None, gt_keypoints=None, input_size: Tuple[int, int] = (192, 256)) -> Dict[str, torch.Tensor]:
+        feats = self.backbone(x)
+        output = dict(self.head(feats)) if self.head_type == "fusion" else {"heatmaps": self.head(feats)}
+        if target is not None:
+            if self.head_type == "fusion" and self.use_fusion_loss and gt_keypoints is not None:
+                H, W = output["heatmaps"].shape[2:]
+                losses = self.loss_fn(output, target, target_weight, gt_keypoints, input_size, (H, W))
+                output["loss"], output["losses"] = losses["total_loss"], losses
+            elif self.head_type == "fusion":
+                raise ValueError("fusion head without gt_keypoints: the reference would call FusionPoseLoss with 3 arguments and fail")
+            else:
+                output["loss"] = self.loss_fn(output["heatmaps"], target, target_weight)
+        return output
+
+    @torch.no_grad()
+    def inference(self, x, flip: bool = True, flip_pairs: Optional[list] = None):
+        """-> keypoints (B,K,2) heat-px, scores (B,K); flip test as pose_estimator.py:275-329 (offsets of the un-flipped pass)."""
+        out = self.forward(x)
+        hm = out["heatmaps"]
+        if flip and flip_pairs is not None:
+            hm_f = self.forward(torch.flip(x, dims=[-1]))["heatmaps"]
+            partner = torch.arange(self.num_keypoints, dtype=torch.int32)
+            for a, b in flip_pairs:
+                partner[a], partner[b] = b, a
+            hm = hipops.flip_merge(hm, hm_f, partner.to(hm.device))
+        if self.head_type == "fusion":
+            o = dict(out)
+            o["heatmaps"] = hm
+            return self.head.decode(o, apply_offset=True)
+        return self.decode_heatmaps(hm)
+
+    @staticmethod
+    @torch.no_grad()
+    def decode_heatmaps(heatmaps, shift: bool = True):
+        _, mv, co = hipops.argmax_decode(heatmaps.float(), 1 if shift else 0)
+        return co, mv
+
+
+def build_model(cfg) -> PoseEstimator:
+    return PoseEstimator(backbone=cfg.model.backbone, num_keypoints=cfg.model.num_keypoints, pretrained=cfg.model.pretrained,
+                         head_type=getattr(cfg.model, "head_type", "fusion"), use_fusion_loss=getattr(cfg.model, "use_fusion_loss", True))

@@ -21,6 +21,11 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")   # only matters while conv is still an ATen/MIOpen stop-gap (nnops.IMPL)
+
+
+def log(msg):
+    print(f"# [{time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
@@ -74,7 +79,8 @@ def cpu_baseline():
     from oracle import train_step as ots
     with open(os.path.join(ROOT, "tests", "golden", "state_keys.json")) as f:
         keys = _json.load(f)
-    cores = os.cpu_count() or 1
+    # the GPU box gives one job a 16-CPU share of a much larger host: use the cores we may actually run on
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
     ips, threads = ots.time_train_steps(keys["hrformer_small_fusion"], keys["hrformer_small_fusion#params"], B=8, steps=3, warmup=1,
                                         input_size=INPUT_SIZE, heatmap_size=HEATMAP_SIZE, K=K, threads=cores)
     return {"value": round(ips, 3), "unit": "images/sec", "cores": threads, "kind": "port",
@@ -102,7 +108,7 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    from infantposeestimation_gaussianbias_amd import engine, nnops
+    from infantposeestimation_gaussianbias_amd import dispatch, engine, nnops, nnops_aten
     from infantposeestimation_gaussianbias_amd.configs import get_config
     from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
     from infantposeestimation_gaussianbias_amd.models import build_model
@@ -115,8 +121,12 @@ def main():
     batch = synthetic_batch(PER_GPU_BATCH, INPUT_SIZE, HEATMAP_SIZE, K, 2.0, dev, seed=1234 + rank)
 
     out = None
-    for _ in range(args.warmup):
+    for i in range(args.warmup):
+        t_w = time.perf_counter()
         out = trainer.step(batch)
+        if rank == 0 and i < 3:
+            torch.cuda.synchronize()
+            log(f"warm-up step {i}: {time.perf_counter() - t_w:.3f} s")
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -132,14 +142,18 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(out["loss"])
+    loss = float(out["loss"].detach())
 
     if rank == 0:
+        log(f"timed region: {dt:.3f} s for {args.steps} steps -> {PER_GPU_BATCH * world * args.steps / dt:.1f} img/s")
         roof = roofline_of_dominant_kernel(batch, out)
+        log(f"roofline kernel timed: {roof}")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
-        n_hip = sum(v == "hip" for v in nnops.IMPL.values())
+            log(f"cpu baseline: {cpu}")
+        impl_table = nnops.IMPL if dispatch.backend_name(model) == "hip" else nnops_aten.IMPL
+        n_hip = sum(v == "hip" for v in impl_table.values())
         line = {
             "metric": "images/sec (train fwd+bwd) HRFormer-S 256x192", "value": round(PER_GPU_BATCH * world * args.steps / dt, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -148,8 +162,8 @@ def main():
             "config": {"workload": "HRFormer-small + fusion head, 256x192 -> 64x48, K=17, train step fwd+bwd+AdamW, DropPath 0.1, BN train",
                        "global_batch": PER_GPU_BATCH * world, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
-            "impl": dict(nnops.IMPL, loss="hip", target="hip", decode="hip", adamw="hip"),
-            "impl_note": f"{n_hip}/{len(nnops.IMPL)} network op groups are hand-written HIP; 'aten' entries are PyTorch-ROCm stop-gaps",
+            "impl": dict(impl_table, loss="hip", target="hip", decode="hip", adamw="hip"),
+            "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP; 'aten' entries are PyTorch-ROCm stop-gaps",
         }
         print(json.dumps(line))
     if world > 1:

@@ -105,6 +105,81 @@ int pk_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
                   uint16_t* param_bf16, int64_t n, const float* lr_dev, const int32_t* step_dev,
                   float beta1, float beta2, float eps, float weight_decay, float grad_scale, void* stream);
 
+
+/* ======================= network contractions (bf16 MFMA, fp32 accumulate; NHWC activations) =======================
+ * These replace the groups of ATen calls inside the reference's modules; weights are bf16 "compute copies" packed by
+ * pk_pack_weights from the fp32 master parameters (which keep the reference's OIHW / (out,in) layouts).            */
+
+/* A5/A6/H1/H2/A4 conv: nn.Conv2d(k=3|1, stride 1|2, padding k/2, bias=False) of models/hrnet.py:24-33,68-79,
+ * models/hrformer.py:309-320,548-551, models/fusion_head.py:211-251 (+ their bias'd 1x1 heads).
+ * x (B,Hs,Ws,Cin) bf16; w_packed [Cout][k*k][Cin] bf16; out_mode 0: (B,Ho,Wo,Cout) bf16, 1: same fp32,
+ * 2: (B,Cout,Ho,Wo) fp32 planes (head outputs).  stats_partial (optional): [pk_conv_stats_tiles(M)][2][Cout] column
+ * sums / sums of squares of the fp32 results for train-mode BatchNorm.  dilated_input=1 evaluates the stride-2
+ * data-gradient (input rows/cols are the zero-stuffed output gradient; pass flipped weights, mode 1 of pk_pack_weights).
+ * act: 0 none, 2 softplus (nn.Softplus of fusion_head.py:250).                                                      */
+int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, float* stats_partial, const float* bias,
+                   int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int dilated_input, int Ho, int Wo,
+                   int act, int out_mode, void* stream);
+int pk_conv_stats_tiles(int M);
+
+/* A1/A3 linear layers: nn.Linear qkv/proj (models/hrformer.py:167-169,180,197) and Mlp fc1/fc2 (:53-55,58-64).
+ * out[o_rowmap[m]] = residual + res_scale[sample] * act(x[a_rowmap[m]] @ w^T + bias).  Row maps implement
+ * window_partition / window_reverse (hrformer.py:67-114) inside the GEMM: a_rowmap -1 = zero pad token, o_rowmap -1 =
+ * cropped token.  act 1 = exact-erf GELU (nn.GELU, hrformer.py:54).  preact_out saves the pre-GELU values;
+ * gelu_grad_of multiplies the result by gelu'(z) (backward through the activation).                                  */
+int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, const void* residual, const float* res_scale,
+                   const int32_t* a_rowmap, const int32_t* o_rowmap, void* preact_out, const void* gelu_grad_of,
+                   int M, int N, int K, int rows_per_sample, int act, int out_fp32, void* stream);
+
+/* weight gradient of either form: dw = sum_m grad_out[m]^T (x) A(m); workspace = pk_wgrad_slices(...)*N*k*k*Cin floats.
+ * out_layout 0: [N][k*k][Cin]; 1: OIHW (the reference's nn.Conv2d.weight layout).  Ho == 0 selects the linear form.   */
+int pk_wgrad_slices(int M, int N, int Cin, int T);
+int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, const int32_t* a_rowmap,
+                  const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M, int N, int Cin, int ksize,
+                  int stride, int B, int Hs, int Ws, int Ho, int Wo, int out_layout, void* stream);
+
+/* window attention core (models/hrformer.py:183-196): softmax(scale*q k^T + table[index]) v per (window, head);
+ * qkv (n_windows*49, 3C) bf16 in the reference's channel order s*C + h*d + e; rel_table (169, heads) fp32.          */
+int pk_window_attn_fwd(const void* qkv, const float* rel_table, void* out, float* lse, int n_windows, int heads, int C, void* stream);
+int pk_window_attn_bwd_groups(int n_windows, int heads);
+int pk_window_attn_bwd_ws_floats(int n_windows, int heads);  /* size of dbias_partial in floats */
+int pk_window_attn_bwd(const void* qkv, const float* rel_table, const void* dout, const float* lse, void* dqkv,
+                       float* dbias_partial, float* dtable, int n_windows, int heads, int C, void* stream);
+
+/* ======================= normalisation / elementwise (HBM-bound, NHWC bf16, 16 bytes per lane) ==================== */
+int pk_sum_partials(const float* partial, int nb, int K, int stride, float* out, float scale, int accumulate, void* stream);
+/* nn.BatchNorm2d train mode (eps 1e-5, momentum 0.1, unbiased running_var): finalize conv-epilogue sums -> scale/shift */
+int pk_bn_finalize(const float* stats_partial, int tiles, int C, int count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                   float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+int pk_bn_act(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
+              int relu, void* stream);                       /* y = relu?(x*scale + shift (+ residual)) */
+int pk_bn_bwd_blocks(int64_t rows);                          /* partial needs blocks*2*C floats */
+int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* save_mean, const float* save_rstd,
+              const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
+              int64_t rows, int C, int relu, void* stream);
+int pk_relu_bwd(const void* dy, const void* y, void* dx, int64_t numel, void* stream);
+/* nn.LayerNorm(C, eps 1e-5) over the channel dim of NHWC rows (hrformer.py:240,252,273,288) */
+int pk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
+                     int64_t rows, int C, float eps, void* stream);
+int pk_ln_bwd_blocks(int64_t rows);                          /* partial needs blocks*2*C floats */
+int pk_layernorm_bwd(const void* dy, const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                     const void* dresidual, void* dx, float* partial, float* dgamma, float* dbeta, int64_t rows, int C, void* stream);
+int pk_colsum_bf16(const void* g, const int32_t* rowmap, const float* row_scale, int rows_per_sample, float* partial,
+                   float* out, int64_t rows, int N, void* stream);
+/* exchange unit sum (hrformer.py:471-489 == hrnet.py:207-225): out = relu?(sum_i bilinear_up_i(x_i)), F.interpolate
+ * (mode='bilinear', align_corners=False) fused into the sum; and the up-sampling backward in gather form.            */
+int pk_fuse_sum(const void* const* inputs, const int* in_h, const int* in_w, int n_inputs, void* out, int B, int H, int W,
+                int C, int relu, void* stream);
+int pk_upsample_bilinear_bwd(const void* dy, void* dsrc, int B, int H, int W, int Hs, int Ws, int C, void* stream);
+int pk_nchw_f32_to_nhwc_bf16(const float* x, const float* softplus_out, void* y, int B, int Cin, int H, int W, int Cpad,
+                             void* stream);   /* softplus_out != NULL: also multiply by d softplus/dz = 1-exp(-y) */
+/* fp32 master weights -> bf16 compute copies, table driven, one launch for the whole model (see nnops.WeightCache).
+ * desc_table: array of {const float* src; int64 dst_off; int N,C,T,mode,Cp,Np; int64 dst_numel} (48 bytes each);
+ * mode 0: dst[n][t][cp]=src[n][c][t] (forward), 1: dst[c][T-1-t][np]=src[n][c][t] (conv data-grad), 2: dst[c][np]=src[n][c] */
+int pk_pack_weights(void* flat_dst_bf16, const void* desc_table, const int32_t* block_desc, const int32_t* block_first,
+                    int n_blocks, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,515 @@
+// Implicit-GEMM on MFMA (bf16 in, fp32 accumulate) for every dense contraction of the network:
+//   3x3 / 1x1 convolutions (forward, and data-gradient as a convolution with flipped weights), and linear layers
+//   with an optional row gather/scatter (window partition / reverse of the HRFormer blocks).
+//
+//   out[m][n] = sum_{t < T} sum_{c < Cin}  A(m, t, c) * Wt[n][t][c]          m < M, n < N
+//     conv   : m = (b,oy,ox), t = (kh,kw), A = X[b][oy*s+kh-p][ox*s+kw-p][c] (0 outside; NHWC)
+//     dilated: A = X[b][(oy+kh-p)/2][(ox+kw-p)/2][c] only where both numerators are even (stride-2 dgrad)
+//     linear : T = 1, A = X[rowmap ? rowmap[m] : m][c]   (rowmap -1 -> zero row: the reference's zero pad tokens)
+//
+// Tiling (one 256-thread workgroup = 4 waves): BM=128 output rows x BN (32/64/128) output columns, K-step 32
+// (one MFMA k), per filter tap.  Operands are staged global -> registers -> LDS (double-buffered, one barrier per
+// K-step, rows padded to 80 B against bank conflicts); fragments are read with 16-byte ds_read and fed to
+// v_mfma_f32_16x16x32_bf16 with the WEIGHT tile as the A operand, so a lane's 4 accumulator registers are 4
+// consecutive output channels of one pixel -> one 8-byte NHWC store per tile per lane.
+//
+// Epilogue options: bias, exact-erf GELU, residual add with a per-sample scale (DropPath), row scatter, bf16 or
+// fp32 output, NCHW-planar fp32 output (head), softplus, and per-tile column sums / sums of squares of the fp32
+// accumulators (train-mode BatchNorm statistics, reduced later in fixed order -> deterministic).
+#include "pk_common.h"
+
+typedef __attribute__((ext_vector_type(8))) short bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define BM 128
+#define BKK 32
+#define LDS_PITCH 40  // bf16 elements per LDS row (32 + 8 pad) = 80 bytes, keeps 16-byte alignment
+
+struct IgemmArgs {
+    const uint16_t* x;        // activations, bf16 NHWC [B][Hs][Ws][Cin] or [rows][Cin]
+    const uint16_t* w;        // weights bf16 [N][T][Cin]
+    void* out;                // see out_mode
+    const float* bias;        // [N] or null
+    const uint16_t* res;      // residual, same layout as a bf16 row-major output, or null
+    const float* res_scale;   // per-sample multiplier of the GEMM result before the residual add, [B] or null
+    const int32_t* a_rowmap;  // [M] source row or -1 (linear mode only), or null
+    const int32_t* o_rowmap;  // [M] destination row or -1 (skip), or null
+    float* stats;             // [gridDim.x][2][N] per-M-tile column sums / sums of squares, or null
+    uint16_t* preact;         // optional bf16 row-major copy of (acc + bias) BEFORE the activation (saved for GELU backward)
+    const uint16_t* gelu_of;  // optional bf16 row-major z: result is multiplied by gelu'(z) (backward through GELU)
+    int M, N, Cin, T;         // T = 1 or 9
+    int Hs, Ws;               // source spatial size (conv)
+    int Ho, Wo;               // output spatial size (conv)
+    int stride, pad, dilated; // conv geometry
+    int ldo;                  // output row pitch in elements (row-major modes)
+    int rows_per_sample;      // rows of one sample (for res_scale): Ho*Wo or tokens per image
+    int act;                  // 0 none, 1 GELU(erf), 2 softplus
+    int out_mode;             // 0 bf16 row-major, 1 fp32 row-major, 2 fp32 NCHW planes [B][N][Ho*Wo]
+};
+
+__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+__device__ __forceinline__ float softplus_(float v) { return v > 20.f ? v : log1pf(__expf(v)); }
+__device__ __forceinline__ float gelu_grad(float z) {
+    return 0.5f * (1.f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+}
+
+template <int BN, int WM, int WN>  // WM x WN waves; wave tile = (BM/WM) x (BN/WN)
+__global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
+    constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
+    constexpr int B_CHUNKS = BN * 4;  // 16-byte chunks of the weight tile
+    __shared__ __attribute__((aligned(16))) uint16_t sA[2][BM * LDS_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t sB[2][BN * LDS_PITCH];
+    __shared__ float sStat[WM][BN][2];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    // ---- per-thread staging descriptors: two A chunks (rows r, r+64; 8 channels at kc*8) and up to two B chunks
+    const int kc = tid & 3;
+    int a_off[2];     // element offset of the row's tap (0,0), channel 0 (conv) or of the row start (linear)
+    int a_iy[2], a_ix[2];
+    bool a_ok[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + (tid >> 2) + 64 * i;
+        a_ok[i] = m < p.M;
+        a_off[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
+        if (!a_ok[i]) continue;
+        if (p.T == 1 && p.Ho == 0) {  // linear
+            int src = p.a_rowmap ? p.a_rowmap[m] : m;
+            a_ok[i] = src >= 0;
+            a_off[i] = src * p.Cin;
+        } else {
+            const int hw = p.Ho * p.Wo, b = m / hw, r = m - b * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
+            a_iy[i] = oy * p.stride - p.pad;
+            a_ix[i] = ox * p.stride - p.pad;
+            a_off[i] = b * p.Hs * p.Ws * p.Cin;
+        }
+    }
+    const bool linear = (p.T == 1 && p.Ho == 0);
+    const int kw_n = (p.T == 9) ? 3 : 1;
+    const int kchunks = (p.Cin + BKK - 1) / BKK;   // K-steps per tap
+    const int nk = p.T * kchunks;
+
+    uint4 ra[2], rb[2];
+    auto load_tiles = [&](int kt) {
+        const int t = kt / kchunks, c0 = (kt - t * kchunks) * BKK + kc * 8;
+        const int kh = t / kw_n, kw = t - kh * kw_n;
+        const bool c_ok = c0 < p.Cin;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a_ok[i] && c_ok) {
+                if (linear) {
+                    v = *reinterpret_cast<const uint4*>(p.x + a_off[i] + c0);
+                } else {
+                    int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
+                    bool ok = true;
+                    if (p.dilated) {
+                        ok = ((iy | ix) & 1) == 0;
+                        iy >>= 1;
+                        ix >>= 1;
+                    }
+                    if (ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
+                        v = *reinterpret_cast<const uint4*>(p.x + a_off[i] + (iy * p.Ws + ix) * p.Cin + c0);
+                }
+            }
+            ra[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + 256 * i;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (ch < B_CHUNKS) {
+                const int n = n0 + (ch >> 2);
+                if (n < p.N && c_ok) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)n * p.T + t) * p.Cin + c0);
+            }
+            rb[i] = v;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<uint4*>(&sA[buf][((tid >> 2) + 64 * i) * LDS_PITCH + kc * 8]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int ch = tid + 256 * i;
+            if (ch < B_CHUNKS) *reinterpret_cast<uint4*>(&sB[buf][(ch >> 2) * LDS_PITCH + kc * 8]) = rb[i];
+        }
+    };
+
+    f32x4 acc[NI][MI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a)
+#pragma unroll
+        for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        bf16x8 wf[NI], af[MI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            wf[a] = *reinterpret_cast<const bf16x8*>(&sB[buf][(wn * (BN / WN) + a * 16 + frow) * LDS_PITCH + fk]);
+#pragma unroll
+        for (int b = 0; b < MI; ++b)
+            af[b] = *reinterpret_cast<const bf16x8*>(&sA[buf][(wm * (BM / WM) + b * 16 + frow) * LDS_PITCH + fk]);
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], af[b], acc[a][b], 0, 0, 0);
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- BatchNorm statistics of the raw fp32 accumulators (rows >= M contribute exact zeros)
+    if (p.stats) {
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float s = 0.f, q = 0.f;
+#pragma unroll
+                for (int b = 0; b < MI; ++b) {
+                    const float v = acc[a][b][r];
+                    s += v;
+                    q += v * v;
+                }
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    s += __shfl_xor(s, o, 64);
+                    q += __shfl_xor(q, o, 64);
+                }
+                if ((lane & 15) == 0) {
+                    const int nl = wn * (BN / WN) + a * 16 + (lane >> 4) * 4 + r;
+                    sStat[wm][nl][0] = s;
+                    sStat[wm][nl][1] = q;
+                }
+            }
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < p.N) {
+            float s = 0.f, q = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) {
+                s += sStat[w][tid][0];
+                q += sStat[w][tid][1];
+            }
+            float* dst = p.stats + (size_t)blockIdx.x * 2 * p.N;
+            dst[n0 + tid] = s;
+            dst[p.N + n0 + tid] = q;
+        }
+    }
+
+    // ---- epilogue
+    const int hw_out = p.Ho * p.Wo;
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+        const int m = m0 + wm * (BM / WM) + b * 16 + (lane & 15);
+        if (m >= p.M) continue;
+        int orow = m;
+        if (p.o_rowmap) {
+            orow = p.o_rowmap[m];
+            if (orow < 0) continue;
+        }
+        float rs = 1.f;
+        if (p.res_scale) rs = p.res_scale[orow / p.rows_per_sample];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) {
+            const int n = n0 + wn * (BN / WN) + a * 16 + (lane >> 4) * 4;
+            if (n >= p.N) continue;
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = acc[a][b][r];
+                if (p.bias && n + r < p.N) t += p.bias[n + r];
+                if (p.preact && n + r < p.N) p.preact[(size_t)orow * p.ldo + n + r] = f32_to_bf16(t);
+                if (p.gelu_of && n + r < p.N) t *= gelu_grad(bf16_to_f32(p.gelu_of[(size_t)orow * p.ldo + n + r]));
+                if (p.act == 1) t = gelu_erf(t);
+                else if (p.act == 2) t = softplus_(t);
+                v[r] = t * rs;
+            }
+            if (p.out_mode == 2) {
+                const int bb = orow / hw_out, pix = orow - bb * hw_out;
+                float* o = reinterpret_cast<float*>(p.out) + ((size_t)bb * p.N + n) * hw_out + pix;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) o[(size_t)r * hw_out] = v[r];
+                continue;
+            }
+            const size_t base = (size_t)orow * p.ldo + n;
+            if (p.res) {
+                if (n + 3 < p.N) {
+                    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + base);
+                    v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
+                    v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += bf16_to_f32(p.res[base + r]);
+                }
+            }
+            if (p.out_mode == 0) {
+                uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + base;
+                if (n + 3 < p.N) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(o) = pk;
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = f32_to_bf16(v[r]);
+                }
+            } else {
+                float* o = reinterpret_cast<float*>(p.out) + base;
+                if (n + 3 < p.N) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = v[r];
+            }
+        }
+    }
+}
+
+static int igemm_launch(const IgemmArgs& a, hipStream_t st, const char* who) {
+    const dim3 block(256);
+    const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
+    if (a.N > 64) {
+        hipLaunchKernelGGL((k_igemm<128, 2, 2>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
+    } else if (a.N > 32) {
+        hipLaunchKernelGGL((k_igemm<64, 4, 1>), dim3(gm, 1), block, 0, st, a);
+    } else {
+        hipLaunchKernelGGL((k_igemm<32, 4, 1>), dim3(gm, 1), block, 0, st, a);
+    }
+    return pk_launch_status(who);
+}
+
+static int check_common(const char* who, const void* x, const void* w, const void* out, int M, int N, int Cin, int ldo,
+                        int out_mode) {
+    PK_REQUIRE(x && w && out, "%s: null pointer", who);
+    PK_REQUIRE(M > 0 && N > 0 && Cin > 0, "%s: bad sizes M=%d N=%d Cin=%d", who, M, N, Cin);
+    PK_SUPPORTED((Cin & 7) == 0, "%s: Cin=%d must be a multiple of 8 (16-byte bf16 chunks)", who, Cin);
+    PK_REQUIRE((((uintptr_t)x | (uintptr_t)w) & 15) == 0, "%s: x/w must be 16-byte aligned", who);
+    if (out_mode != 2) {
+        PK_REQUIRE(ldo >= N, "%s: ldo=%d < N=%d", who, ldo, N);
+        PK_REQUIRE((ldo & 3) == 0 && ((uintptr_t)out & 15) == 0, "%s: output pitch must be a multiple of 4 and 16-byte aligned", who);
+    }
+    PK_REQUIRE((int64_t)M * (ldo > Cin ? ldo : Cin) < 0x7fffffffLL, "%s: tensor too large for 32-bit offsets", who);
+    return PK_OK;
+}
+
+extern "C" int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, float* stats_partial, const float* bias,
+                              int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int dilated_input, int Ho,
+                              int Wo, int act, int out_mode, void* stream) {
+    const int M = B * Ho * Wo;
+    int rc = check_common("pk_conv2d_nhwc", x, w_packed, out, M, Cout, Cin, Cout, out_mode);
+    if (rc) return rc;
+    PK_REQUIRE(ksize == 1 || ksize == 3, "pk_conv2d_nhwc: ksize %d", ksize);
+    PK_REQUIRE(stride == 1 || (stride == 2 && !dilated_input), "pk_conv2d_nhwc: stride %d", stride);
+    PK_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "pk_conv2d_nhwc: bad geometry");
+    if (dilated_input) {
+        PK_REQUIRE(Ho <= 2 * Hs && Wo <= 2 * Ws && Ho >= 2 * Hs - 1 && Wo >= 2 * Ws - 1, "pk_conv2d_nhwc: dilated geometry %dx%d <- %dx%d", Ho, Wo, Hs, Ws);
+    } else {
+        const int pad = ksize / 2;
+        PK_REQUIRE(Ho == (Hs + 2 * pad - ksize) / stride + 1 && Wo == (Ws + 2 * pad - ksize) / stride + 1,
+                   "pk_conv2d_nhwc: output %dx%d does not match input %dx%d k=%d s=%d", Ho, Wo, Hs, Ws, ksize, stride);
+    }
+    PK_REQUIRE(out_mode >= 0 && out_mode <= 2 && act >= 0 && act <= 2, "pk_conv2d_nhwc: bad mode");
+    PK_REQUIRE((int64_t)B * Hs * Ws * Cin < 0x7fffffffLL, "pk_conv2d_nhwc: input too large for 32-bit offsets");
+    PK_REQUIRE(out_mode == 2 || (Cout & 3) == 0, "pk_conv2d_nhwc: Cout=%d must be a multiple of 4 for row-major output", Cout);
+    IgemmArgs a{};
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_packed; a.out = out; a.bias = bias; a.stats = stats_partial;
+    a.M = M; a.N = Cout; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo;
+    a.stride = stride; a.pad = ksize / 2; a.dilated = dilated_input; a.ldo = Cout; a.rows_per_sample = Ho * Wo;
+    a.act = act; a.out_mode = out_mode;
+    return igemm_launch(a, (hipStream_t)stream, "pk_conv2d_nhwc");
+}
+
+extern "C" int pk_conv_stats_tiles(int M) { return (M + BM - 1) / BM; }
+
+extern "C" int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, const void* residual,
+                              const float* res_scale, const int32_t* a_rowmap, const int32_t* o_rowmap, void* preact_out,
+                              const void* gelu_grad_of, int M, int N, int K, int rows_per_sample, int act, int out_fp32,
+                              void* stream) {
+    int rc = check_common("pk_linear_bf16", x, w, out, M, N, K, N, out_fp32 ? 1 : 0);
+    if (rc) return rc;
+    PK_REQUIRE((N & 3) == 0, "pk_linear_bf16: N=%d must be a multiple of 4", N);
+    PK_REQUIRE(!res_scale || rows_per_sample > 0, "pk_linear_bf16: res_scale needs rows_per_sample");
+    PK_REQUIRE(act >= 0 && act <= 1, "pk_linear_bf16: act %d", act);
+    IgemmArgs a{};
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w; a.out = out; a.bias = bias; a.res = (const uint16_t*)residual;
+    a.res_scale = res_scale; a.a_rowmap = a_rowmap; a.o_rowmap = o_rowmap;
+    a.preact = (uint16_t*)preact_out; a.gelu_of = (const uint16_t*)gelu_grad_of;
+    a.M = M; a.N = N; a.Cin = K; a.T = 1; a.Ho = 0; a.Wo = 0; a.ldo = N; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1;
+    a.act = act; a.out_mode = out_fp32 ? 1 : 0;
+    return igemm_launch(a, (hipStream_t)stream, "pk_linear_bf16");
+}
+
+// ================================================================================================ weight gradient
+// dW[n][t][c] = sum_m G(m, n) * A(m, t, c):  the contraction runs over pixels/tokens m, so both operands are staged
+// TRANSPOSED in LDS ([n][m] and [c][m], 16-byte fragment reads along m).  One workgroup owns a 64(n) x 64(c) tile of
+// one filter tap and one slice of M (split-M over gridDim.z); slices are written to an fp32 workspace and summed in
+// fixed order by k_wgrad_reduce (deterministic, no float atomics).
+struct WgradArgs {
+    const uint16_t* x;   // activations (layer input) bf16
+    const uint16_t* g;   // output gradient bf16 [rows][N]
+    float* part;         // [S][N][T][Cin] fp32
+    const int32_t* a_rowmap;  // source row of x for GEMM row m (linear), -1 = zero row
+    const int32_t* g_rowmap;  // source row of g for GEMM row m, -1 = zero row
+    const float* g_scale;     // optional per-sample multiplier of g rows (DropPath), indexed by g_row / g_rows_per_sample
+    int g_rows_per_sample;
+    int M, N, Cin, T, Hs, Ws, Ho, Wo, stride, pad, m_per_slice, ctiles;
+};
+
+#define WG_MK 32
+#define WG_PITCH 40
+
+__global__ void __launch_bounds__(256) k_wgrad(WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) uint16_t sG[2][64 * WG_PITCH];
+    __shared__ __attribute__((aligned(16))) uint16_t sX[2][64 * WG_PITCH];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntile = blockIdx.x / p.ctiles, ctile = blockIdx.x - ntile * p.ctiles;
+    const int n0 = ntile * 64, c0 = ctile * 64, t = blockIdx.y;
+    const int kw_n = (p.T == 9) ? 3 : 1, kh = t / kw_n, kw = t - kh * kw_n;
+    const int m_begin = blockIdx.z * p.m_per_slice;
+    const int m_end = min(p.M, m_begin + p.m_per_slice);
+    const bool linear = (p.Ho == 0);
+    const int row = tid & 31, chunk = tid >> 5;   // one 16-byte chunk of G and one of X per thread per step
+    const int hw = p.Ho * p.Wo;
+
+    uint4 rg, rx;
+    auto load = [&](int ms) {
+        const int m = ms + row;
+        rg = make_uint4(0, 0, 0, 0);
+        rx = make_uint4(0, 0, 0, 0);
+        if (m >= m_end) return;
+        const int n = n0 + chunk * 8, c = c0 + chunk * 8;
+        if (n < p.N) {
+            const int gr = p.g_rowmap ? p.g_rowmap[m] : m;
+            if (gr >= 0) {
+                rg = *reinterpret_cast<const uint4*>(p.g + (size_t)gr * p.N + n);
+                if (p.g_scale) {
+                    const float sc = p.g_scale[gr / p.g_rows_per_sample];
+                    uint16_t* e = reinterpret_cast<uint16_t*>(&rg);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16(bf16_to_f32(e[j]) * sc);
+                }
+            }
+        }
+        if (c < p.Cin) {
+            if (linear) {
+                const int xr = p.a_rowmap ? p.a_rowmap[m] : m;
+                if (xr >= 0) rx = *reinterpret_cast<const uint4*>(p.x + (size_t)xr * p.Cin + c);
+            } else {
+                const int b = m / hw, r = m - b * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
+                const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+                if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
+                    rx = *reinterpret_cast<const uint4*>(p.x + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + c);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+        const uint16_t* vg = reinterpret_cast<const uint16_t*>(&rg);
+        const uint16_t* vx = reinterpret_cast<const uint16_t*>(&rx);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            sG[buf][(chunk * 8 + j) * WG_PITCH + row] = vg[j];
+            sX[buf][(chunk * 8 + j) * WG_PITCH + row] = vx[j];
+        }
+    };
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wn = wave >> 1, wc = wave & 1;      // 2 x 2 waves, 32 x 32 each
+    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    const int nsteps = (m_end - m_begin + WG_MK - 1) / WG_MK;
+    if (nsteps > 0) {
+        load(m_begin);
+        store(0);
+    }
+    __syncthreads();
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < nsteps) load(m_begin + (s + 1) * WG_MK);
+        bf16x8 gf[2], xf[2];
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+            gf[a] = *reinterpret_cast<const bf16x8*>(&sG[buf][(wn * 32 + a * 16 + frow) * WG_PITCH + fk]);
+            xf[a] = *reinterpret_cast<const bf16x8*>(&sX[buf][(wc * 32 + a * 16 + frow) * WG_PITCH + fk]);
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
+        if (s + 1 < nsteps) store(buf ^ 1);
+        __syncthreads();
+    }
+    float* dst = p.part + (size_t)blockIdx.z * p.N * p.T * p.Cin;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int c = c0 + wc * 32 + b * 16 + (lane & 15);
+            if (c >= p.Cin) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int n = n0 + wn * 32 + a * 16 + (lane >> 4) * 4 + r;
+                if (n < p.N) dst[((size_t)n * p.T + t) * p.Cin + c] = acc[a][b][r];
+            }
+        }
+}
+
+// out[...] = sum_s part[s][n][t][c]; layout 0: [N][T][Cin]; layout 1: OIHW = [N][Cin][T] (reference conv weight layout)
+__global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ out, int S, int N, int T,
+                                                      int Cin, int layout) {
+    const int total = N * T * Cin;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < S; ++k) s += part[(size_t)k * total + i];
+        if (layout == 0) out[i] = s;
+        else {
+            const int c = i % Cin, t = (i / Cin) % T, n = i / (Cin * T);
+            out[((size_t)n * Cin + c) * T + t] = s;
+        }
+    }
+}
+
+extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
+    // enough workgroups to fill 256 CUs several times over, but no slice shorter than 512 rows
+    const int tiles = ((N + 63) / 64) * ((Cin + 63) / 64) * T;
+    int s = (2048 + tiles - 1) / tiles;
+    const int max_s = (M + 511) / 512;
+    if (s > max_s) s = max_s;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+
+extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, const int32_t* a_rowmap,
+                             const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M, int N, int Cin, int ksize,
+                             int stride, int B, int Hs, int Ws, int Ho, int Wo, int out_layout, void* stream) {
+    PK_REQUIRE(x && grad_out && workspace && dw, "pk_wgrad_bf16: null pointer");
+    PK_REQUIRE(M > 0 && N > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "pk_wgrad_bf16: bad sizes");
+    PK_SUPPORTED((Cin & 7) == 0 && (N & 7) == 0, "pk_wgrad_bf16: Cin=%d and N=%d must be multiples of 8", Cin, N);
+    const bool linear = (Ho == 0);
+    if (!linear) PK_REQUIRE(M == B * Ho * Wo && (int64_t)B * Hs * Ws * Cin < 0x7fffffffLL, "pk_wgrad_bf16: geometry");
+    PK_REQUIRE(linear || (!a_rowmap && !g_rowmap), "pk_wgrad_bf16: row maps are for the linear form only");
+    WgradArgs a{};
+    PK_REQUIRE(!g_scale || g_rows_per_sample > 0, "pk_wgrad_bf16: g_scale needs g_rows_per_sample");
+    a.x = (const uint16_t*)x; a.g = (const uint16_t*)grad_out; a.part = workspace; a.a_rowmap = a_rowmap; a.g_rowmap = g_rowmap;
+    a.g_scale = g_scale; a.g_rows_per_sample = g_rows_per_sample > 0 ? g_rows_per_sample : 1;
+    a.M = M; a.N = N; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = ksize / 2;
+    const int S = pk_wgrad_slices(M, N, Cin, a.T);
+    a.m_per_slice = ((M + S - 1) / S + WG_MK - 1) / WG_MK * WG_MK;
+    a.ctiles = (Cin + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_wgrad, dim3(((N + 63) / 64) * a.ctiles, a.T, S), dim3(256), 0, st, a);
+    const int total = N * a.T * Cin;
+    int nb = (total + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(nb), dim3(256), 0, st, workspace, dw, S, N, a.T, Cin, out_layout);
+    return pk_launch_status("pk_wgrad_bf16");
+}

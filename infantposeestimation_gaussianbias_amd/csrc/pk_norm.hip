@@ -1,0 +1,662 @@
+// HBM-bound kernels around the MFMA contractions: BatchNorm (train statistics finalize / apply / backward),
+// LayerNorm (forward / backward), exchange-unit sum with bilinear up-sampling, input layout conversion, weight
+// packing.  All operate on NHWC bf16 rows of C channels, 8 channels (16 bytes) per lane.
+#include "pk_common.h"
+
+__device__ __forceinline__ void unpack8(const uint4& v, float* f) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __uint_as_float(w[i] << 16);
+        f[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+    }
+}
+__device__ __forceinline__ uint4 pack8(const float* f) {
+    uint4 v;
+    v.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
+    v.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
+    v.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
+    v.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    return v;
+}
+
+// ================================================================================================ generic partial sums
+// out[k] (+)= scale * sum_b partial[b*stride + k], k < K.  Block = 16 columns x 16 row-lanes: lane r sums rows b = r (mod 16),
+// the 16 lane sums are combined in fixed order -> deterministic, and the serial chain is nb/16 instead of nb.
+__global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ part, int nb, int K, int stride, float* __restrict__ out,
+                                                      float scale, int accumulate) {
+    __shared__ double sh[16][17];
+    const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int k = blockIdx.x * 16 + col;
+    double s = 0.0;
+    if (k < K)
+        for (int b = rl; b < nb; b += 16) s += (double)part[(size_t)b * stride + k];
+    sh[rl][col] = s;
+    __syncthreads();
+    if (rl == 0 && k < K) {
+        double t = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += sh[r][col];
+        const float v = (float)t * scale;
+        out[k] = accumulate ? out[k] + v : v;
+    }
+}
+#define SUM_PARTIALS_GRID(K) dim3(((K) + 15) / 16)
+extern "C" int pk_sum_partials(const float* partial, int nb, int K, int stride, float* out, float scale, int accumulate, void* stream) {
+    PK_REQUIRE(partial && out && nb > 0 && K > 0 && stride >= K, "pk_sum_partials: bad argument");
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(K), dim3(256), 0, (hipStream_t)stream, partial, nb, K, stride, out, scale, accumulate);
+    return pk_launch_status("pk_sum_partials");
+}
+
+// ================================================================================================ BatchNorm (train)
+// Finalize the per-tile column sums written by the conv epilogue: batch mean / biased var -> scale, shift for the
+// apply kernel, saved mean / rstd for backward, running stats (momentum 0.1, UNBIASED var), num_batches_tracked += 1.
+__global__ void __launch_bounds__(256) k_bn_finalize(const float* __restrict__ part, int tiles, int C, float count,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ run_mean, float* __restrict__ run_var,
+                                                     long long* __restrict__ nbt, float momentum, float eps,
+                                                     float* __restrict__ scale, float* __restrict__ shift,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    // block = 16 channels x 16 tile-lanes; fixed-order combination of the lane sums (deterministic)
+    __shared__ double sh[2][16][17];
+    const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + col;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+    double s = 0.0, q = 0.0;
+    if (c < C)
+        for (int t = rl; t < tiles; t += 16) {
+            s += (double)part[(size_t)t * 2 * C + c];
+            q += (double)part[(size_t)t * 2 * C + C + c];
+        }
+    sh[0][rl][col] = s;
+    sh[1][rl][col] = q;
+    __syncthreads();
+    if (rl != 0 || c >= C) return;
+    s = 0.0; q = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        s += sh[0][r][col];
+        q += sh[1][r][col];
+    }
+    const double mean = s / count;
+    double var = q / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float g = gamma[c];
+    scale[c] = g * rstd;
+    shift[c] = beta[c] - (float)mean * g * rstd;
+    mean_out[c] = (float)mean;
+    rstd_out[c] = rstd;
+    if (run_mean) {
+        const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+        run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+        run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+    }
+}
+extern "C" int pk_bn_finalize(const float* stats_partial, int tiles, int C, int count, const float* gamma, const float* beta,
+                              float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
+                              float* scale, float* shift, float* save_mean, float* save_rstd, void* stream) {
+    PK_REQUIRE(stats_partial && gamma && beta && scale && shift && save_mean && save_rstd, "pk_bn_finalize: null pointer");
+    PK_REQUIRE(tiles > 0 && C > 0 && count > 0, "pk_bn_finalize: bad sizes");
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats_partial, tiles, C, (float)count,
+                       gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, scale, shift, save_mean,
+                       save_rstd);
+    return pk_launch_status("pk_bn_finalize");
+}
+
+// y = act(x*scale[c] + shift[c] (+ residual)); one 16-byte chunk per thread-iteration
+__global__ void __launch_bounds__(256) k_bn_act(const uint4* __restrict__ x, const float* __restrict__ scale,
+                                                const float* __restrict__ shift, const uint4* __restrict__ res, uint4* __restrict__ y,
+                                                size_t chunks, int cchunks, int relu) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cchunks) * 8;
+        float v[8], r[8];
+        unpack8(x[i], v);
+        if (res) unpack8(res[i], r);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = v[j] * scale[c0 + j] + shift[c0 + j];
+            if (res) t += r[j];
+            v[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        y[i] = pack8(v);
+    }
+}
+extern "C" int pk_bn_act(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
+                         int relu, void* stream) {
+    PK_REQUIRE(x && scale && shift && y && rows > 0 && C > 0 && (C & 7) == 0, "pk_bn_act: bad argument (C=%d)", C);
+    const size_t chunks = (size_t)rows * (C / 8);
+    size_t nb = (chunks + 255) / 256;
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(k_bn_act, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, scale, shift,
+                       (const uint4*)residual, (uint4*)y, chunks, C / 8, relu);
+    return pk_launch_status("pk_bn_act");
+}
+
+// Backward, pass 1: per-block partial sums over rows of g and g*xhat, g = dy * (y > 0 if relu).
+// Block = 256 threads = (256/cchunks) row lanes x cchunks channel chunks; partial[block][2][C].
+#define BNR_MAXC 1024
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
+                                                       const uint4* __restrict__ raw, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ part, int64_t rows, int C,
+                                                       int relu, int rows_per_block) {
+    __shared__ float sh[256 * 16];
+    const int cchunks = C / 8, rlanes = 256 / cchunks;
+    const int cc = threadIdx.x % cchunks, rl = threadIdx.x / cchunks;
+    float s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float mu[8], rs[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        mu[j] = mean[cc * 8 + j];
+        rs[j] = rstd[cc * 8 + j];
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + (int64_t)rows_per_block);
+    if (rl < rlanes) {
+        for (int64_t r = r0 + rl; r < r1; r += rlanes) {
+            const size_t i = (size_t)r * cchunks + cc;
+            float g[8], xr[8], ya[8];
+            unpack8(dy[i], g);
+            unpack8(raw[i], xr);
+            if (relu) unpack8(yact[i], ya);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float gg = (relu && !(ya[j] > 0.f)) ? 0.f : g[j];
+                s1[j] += gg;
+                s2[j] += gg * (xr[j] - mu[j]) * rs[j];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sh[threadIdx.x * 16 + j] = s1[j];
+        sh[threadIdx.x * 16 + 8 + j] = s2[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < cchunks) {
+        float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < rlanes; ++k) {
+            const int t = k * cchunks + threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a1[j] += sh[t * 16 + j];
+                a2[j] += sh[t * 16 + 8 + j];
+            }
+        }
+        float* dst = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dst[threadIdx.x * 8 + j] = a1[j];
+            dst[C + threadIdx.x * 8 + j] = a2[j];
+        }
+    }
+}
+// Backward, pass 2: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); optional d_residual = g
+__global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
+                                                      const uint4* __restrict__ raw, const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                      const float* __restrict__ sums, float inv_count, uint4* __restrict__ dx,
+                                                      uint4* __restrict__ dres, size_t chunks, int cchunks, int relu) {
+    const int C = cchunks * 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+        const int c0 = (int)(i % cchunks) * 8;
+        float g[8], xr[8], ya[8], o[8];
+        unpack8(dy[i], g);
+        unpack8(raw[i], xr);
+        if (relu) unpack8(yact[i], ya);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = c0 + j;
+            const float gg = (relu && !(ya[j] > 0.f)) ? 0.f : g[j];
+            g[j] = gg;
+            const float xh = (xr[j] - mean[c]) * rstd[c];
+            o[j] = gamma[c] * rstd[c] * (gg - sums[c] * inv_count - xh * sums[C + c] * inv_count);
+        }
+        dx[i] = pack8(o);
+        if (dres) dres[i] = pack8(g);
+    }
+}
+extern "C" int pk_bn_bwd_blocks(int64_t rows) {
+    int64_t nb = (rows + 255) / 256;
+    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+}
+extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* save_mean, const float* save_rstd,
+                         const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
+                         int64_t rows, int C, int relu, void* stream) {
+    PK_REQUIRE(dy && raw && save_mean && save_rstd && gamma && partial && sums && dgamma && dbeta && dx, "pk_bn_bwd: null pointer");
+    PK_REQUIRE(!relu || y_act, "pk_bn_bwd: relu needs the activated output");
+    PK_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0, "pk_bn_bwd: bad sizes");
+    PK_SUPPORTED(C <= BNR_MAXC && C / 8 <= 256, "pk_bn_bwd: C=%d too large", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = pk_bn_bwd_blocks(rows);
+    const int rpb = (int)((rows + nb - 1) / nb);
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw, save_mean,
+                       save_rstd, partial, rows, C, relu, rpb);
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0);
+    // dbeta = sum g ; dgamma = sum g*xhat  (copied out of `sums`, which the apply kernel also reads)
+    hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    const size_t chunks = (size_t)rows * (C / 8);
+    size_t gb = (chunks + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)gb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw,
+                       save_mean, save_rstd, gamma, sums, 1.f / (float)rows, (uint4*)dx, (uint4*)dresidual, chunks, C / 8, relu);
+    return pk_launch_status("pk_bn_bwd");
+}
+
+// relu backward alone (exchange-unit output / plain masks): dx = dy * (y > 0)
+__global__ void __launch_bounds__(256) k_relu_bwd(const uint4* __restrict__ dy, const uint4* __restrict__ y, uint4* __restrict__ dx,
+                                                  size_t chunks) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+        float g[8], v[8];
+        unpack8(dy[i], g);
+        unpack8(y[i], v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) g[j] = v[j] > 0.f ? g[j] : 0.f;
+        dx[i] = pack8(g);
+    }
+}
+extern "C" int pk_relu_bwd(const void* dy, const void* y, void* dx, int64_t numel, void* stream) {
+    PK_REQUIRE(dy && y && dx && numel > 0 && (numel & 7) == 0, "pk_relu_bwd: bad argument");
+    const size_t chunks = (size_t)numel / 8;
+    size_t gb = (chunks + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_relu_bwd, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, (const uint4*)dy, (const uint4*)y, (uint4*)dx, chunks);
+    return pk_launch_status("pk_relu_bwd");
+}
+
+// ================================================================================================ LayerNorm
+// Row of C channels handled by L = pow2 >= C/8 lanes (8 channels per lane); 64/L rows per wave.
+template <int L>
+__global__ void __launch_bounds__(256) k_ln_fwd(const uint4* __restrict__ x, const float* __restrict__ gamma,
+                                                const float* __restrict__ beta, uint4* __restrict__ y, float* __restrict__ mean_out,
+                                                float* __restrict__ rstd_out, int64_t rows, int C, float eps) {
+    const int cchunks = C / 8, sub = threadIdx.x % L;
+    const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / L;
+    const bool on = row < rows && sub < cchunks;
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (on) unpack8(x[(size_t)row * cchunks + sub], v);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
+#pragma unroll
+    for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    if (on) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q += (v[j] - mean) * (v[j] - mean);
+    }
+#pragma unroll
+    for (int o = 1; o < L; o <<= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    if (!on) return;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * rstd * gamma[sub * 8 + j] + beta[sub * 8 + j];
+    y[(size_t)row * cchunks + sub] = pack8(v);
+    if (sub == 0) {
+        mean_out[row] = mean;
+        rstd_out[row] = rstd;
+    }
+}
+#define LN_DISPATCH(KERNEL, L, ...)                                                                                     \
+    do {                                                                                                                \
+        const int64_t threads = rows * (L);                                                                             \
+        hipLaunchKernelGGL((KERNEL<L>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, __VA_ARGS__);        \
+    } while (0)
+static int ln_lanes(int C) {
+    int l = 1;
+    while (l * 8 < C) l <<= 1;
+    return l;
+}
+extern "C" int pk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
+                                int64_t rows, int C, float eps, void* stream) {
+    PK_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && rows > 0, "pk_layernorm_fwd: bad argument");
+    PK_SUPPORTED(C >= 8 && (C & 7) == 0 && C <= 512, "pk_layernorm_fwd: C=%d (need a multiple of 8, <= 512)", C);
+    hipStream_t st = (hipStream_t)stream;
+    const uint4* X = (const uint4*)x;
+    uint4* Y = (uint4*)y;
+    switch (ln_lanes(C)) {
+        case 1: LN_DISPATCH(k_ln_fwd, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
+        case 2: LN_DISPATCH(k_ln_fwd, 2, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
+        case 4: LN_DISPATCH(k_ln_fwd, 4, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
+        case 8: LN_DISPATCH(k_ln_fwd, 8, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
+        case 16: LN_DISPATCH(k_ln_fwd, 16, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
+        case 32: LN_DISPATCH(k_ln_fwd, 32, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
+        default: LN_DISPATCH(k_ln_fwd, 64, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
+    }
+    return pk_launch_status("pk_layernorm_fwd");
+}
+
+// dx = rstd*(gh - mean_c(gh) - xhat*mean_c(gh*xhat)) (+ dres), gh = dy*gamma; per-block partials of dgamma/dbeta.
+// Each block owns `rows_per_block` consecutive rows so its column partials can be reduced deterministically.
+template <int L>
+__global__ void __launch_bounds__(256) k_ln_bwd(const uint4* __restrict__ dy, const uint4* __restrict__ x, const float* __restrict__ mean,
+                                                const float* __restrict__ rstd, const float* __restrict__ gamma,
+                                                const uint4* __restrict__ dres, uint4* __restrict__ dx, float* __restrict__ part,
+                                                int64_t rows, int C, int rows_per_block) {
+    __shared__ float sh[256 * 16];
+    const int cchunks = C / 8, sub = threadIdx.x % L, rl = threadIdx.x / L, rlanes = 256 / L;
+    float ag[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ab[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gm[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) gm[j] = (sub < cchunks) ? gamma[sub * 8 + j] : 0.f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + (int64_t)rows_per_block);
+    for (int64_t rb = r0; rb < r1; rb += rlanes) {        // uniform trip count: every lane executes the shuffles
+        const int64_t row = rb + rl;
+        const bool on = row < r1 && sub < cchunks;
+        float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xh[8];
+        float mu = 0.f, rs = 0.f;
+        if (on) {
+            unpack8(dy[(size_t)row * cchunks + sub], g);
+            unpack8(x[(size_t)row * cchunks + sub], v);
+            mu = mean[row];
+            rs = rstd[row];
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            xh[j] = (v[j] - mu) * rs;
+            const float gh = g[j] * gm[j];
+            s1 += gh;
+            s2 += gh * xh[j];
+            ag[j] += g[j] * xh[j];
+            ab[j] += g[j];
+        }
+#pragma unroll
+        for (int o = 1; o < L; o <<= 1) {
+            s1 += __shfl_xor(s1, o, 64);
+            s2 += __shfl_xor(s2, o, 64);
+        }
+        if (on) {
+            float o8[8], r8[8];
+            if (dres) unpack8(dres[(size_t)row * cchunks + sub], r8);
+            const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                o8[j] = rs * (g[j] * gm[j] - m1 - xh[j] * m2);
+                if (dres) o8[j] += r8[j];
+            }
+            dx[(size_t)row * cchunks + sub] = pack8(o8);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sh[threadIdx.x * 16 + j] = ag[j];
+        sh[threadIdx.x * 16 + 8 + j] = ab[j];
+    }
+    __syncthreads();
+    if (threadIdx.x < cchunks) {
+        float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < rlanes; ++k) {
+            const int t = k * L + threadIdx.x;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                a1[j] += sh[t * 16 + j];
+                a2[j] += sh[t * 16 + 8 + j];
+            }
+        }
+        float* dst = part + (size_t)blockIdx.x * 2 * C;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            dst[threadIdx.x * 8 + j] = a1[j];
+            dst[C + threadIdx.x * 8 + j] = a2[j];
+        }
+    }
+}
+extern "C" int pk_ln_bwd_blocks(int64_t rows) {
+    int64_t nb = (rows + 511) / 512;
+    return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+}
+extern "C" int pk_layernorm_bwd(const void* dy, const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
+                                const void* dresidual, void* dx, float* partial, float* dgamma, float* dbeta, int64_t rows, int C,
+                                void* stream) {
+    PK_REQUIRE(dy && x && save_mean && save_rstd && gamma && dx && partial && dgamma && dbeta && rows > 0, "pk_layernorm_bwd: bad argument");
+    PK_SUPPORTED(C >= 8 && (C & 7) == 0 && C <= 512, "pk_layernorm_bwd: C=%d", C);
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = pk_ln_bwd_blocks(rows);
+    const int rpb = (int)((rows + nb - 1) / nb);
+    const uint4 *DY = (const uint4*)dy, *X = (const uint4*)x, *DR = (const uint4*)dresidual;
+    uint4* DX = (uint4*)dx;
+#define LNB(L) hipLaunchKernelGGL((k_ln_bwd<L>), dim3(nb), dim3(256), 0, st, DY, X, save_mean, save_rstd, gamma, DR, DX, partial, rows, C, rpb)
+    switch (ln_lanes(C)) {
+        case 1: LNB(1); break;
+        case 2: LNB(2); break;
+        case 4: LNB(4); break;
+        case 8: LNB(8); break;
+        case 16: LNB(16); break;
+        case 32: LNB(32); break;
+        default: LNB(64); break;
+    }
+#undef LNB
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(C), dim3(256), 0, st, partial, nb, C, 2 * C, dgamma, 1.f, 0);
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(C), dim3(256), 0, st, partial + C, nb, C, 2 * C, dbeta, 1.f, 0);
+    return pk_launch_status("pk_layernorm_bwd");
+}
+
+// column sums of a bf16 [rows][N] matrix (bias gradients): partial[block][N] then k_sum_partials
+__global__ void __launch_bounds__(256) k_colsum(const uint4* __restrict__ g, const int32_t* __restrict__ rowmap, float* __restrict__ part,
+                                                int64_t rows, int N, int rows_per_block, const float* __restrict__ row_scale,
+                                                int rows_per_sample) {
+    __shared__ float sh[256 * 8];
+    const int cchunks = N / 8, rlanes = 256 / cchunks;
+    const int cc = threadIdx.x % cchunks, rl = threadIdx.x / cchunks;
+    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + (int64_t)rows_per_block);
+    if (rl < rlanes)
+        for (int64_t r = r0 + rl; r < r1; r += rlanes) {
+            const int64_t src = rowmap ? rowmap[r] : r;
+            if (src < 0) continue;
+            float v[8];
+            unpack8(g[(size_t)src * cchunks + cc], v);
+            const float sc = row_scale ? row_scale[src / rows_per_sample] : 1.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] += v[j] * sc;
+        }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sh[threadIdx.x * 8 + j] = a[j];
+    __syncthreads();
+    if (threadIdx.x < cchunks) {
+        float s[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < rlanes; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] += sh[(k * cchunks + threadIdx.x) * 8 + j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part[(size_t)blockIdx.x * N + threadIdx.x * 8 + j] = s[j];
+    }
+}
+extern "C" int pk_colsum_bf16(const void* g, const int32_t* rowmap, const float* row_scale, int rows_per_sample, float* partial,
+                              float* out, int64_t rows, int N, void* stream) {
+    PK_REQUIRE(g && partial && out && rows > 0 && N > 0 && (N & 7) == 0, "pk_colsum_bf16: bad argument");
+    PK_REQUIRE(!row_scale || rows_per_sample > 0, "pk_colsum_bf16: row_scale needs rows_per_sample");
+    PK_SUPPORTED(N / 8 <= 256, "pk_colsum_bf16: N=%d too wide", N);
+    const int nb = pk_ln_bwd_blocks(rows);
+    const int rpb = (int)((rows + nb - 1) / nb);
+    hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, rowmap, partial, rows, N, rpb, row_scale,
+                       rows_per_sample > 0 ? rows_per_sample : 1);
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(N), dim3(256), 0, (hipStream_t)stream, partial, nb, N, N, out, 1.f, 0);
+    return pk_launch_status("pk_colsum_bf16");
+}
+
+// ================================================================================================ exchange-unit sum
+// out = relu?( sum_i up_i(x_i) ): every input is NHWC bf16 with the same C; input i has spatial size (H>>s_i, W>>s_i)
+// ... in general (Hi, Wi) and is bilinearly up-sampled (align_corners=False) to (H, W) when smaller.
+struct FuseIn { const uint16_t* p; int H, W; };
+struct FuseArgs { FuseIn in[4]; int n; uint16_t* out; int B, H, W, C, relu; };
+__device__ __forceinline__ void bil_taps(int o, int n_in, int n_out, int& i0, int& i1, float& f) {
+    float s = ((float)o + 0.5f) * ((float)n_in / (float)n_out) - 0.5f;
+    s = fmaxf(s, 0.f);
+    i0 = min((int)s, n_in - 1);
+    i1 = min(i0 + 1, n_in - 1);
+    f = s - (float)i0;
+}
+__global__ void __launch_bounds__(256) k_fuse_sum(FuseArgs a) {
+    const int cchunks = a.C / 8;
+    const size_t chunks = (size_t)a.B * a.H * a.W * cchunks;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cchunks);
+        size_t pix = i / cchunks;
+        const int x = (int)(pix % a.W);
+        pix /= a.W;
+        const int y = (int)(pix % a.H), b = (int)(pix / a.H);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int k = 0; k < a.n; ++k) {
+            const FuseIn& in = a.in[k];
+            float v[8];
+            if (in.H == a.H && in.W == a.W) {
+                unpack8(*reinterpret_cast<const uint4*>(in.p + (((size_t)b * a.H + y) * a.W + x) * a.C + cc * 8), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += v[j];
+            } else {
+                int y0, y1, x0, x1;
+                float fy, fx;
+                bil_taps(y, in.H, a.H, y0, y1, fy);
+                bil_taps(x, in.W, a.W, x0, x1, fx);
+                const uint16_t* base = in.p + (size_t)b * in.H * in.W * a.C + cc * 8;
+                float v01[8], v10[8], v11[8];
+                unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y0 * in.W + x0) * a.C), v);
+                unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y0 * in.W + x1) * a.C), v01);
+                unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y1 * in.W + x0) * a.C), v10);
+                unpack8(*reinterpret_cast<const uint4*>(base + ((size_t)y1 * in.W + x1) * a.C), v11);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    acc[j] += (v[j] * (1.f - fx) + v01[j] * fx) * (1.f - fy) + (v10[j] * (1.f - fx) + v11[j] * fx) * fy;
+            }
+        }
+        if (a.relu) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] = fmaxf(acc[j], 0.f);
+        }
+        *reinterpret_cast<uint4*>(a.out + i * 8) = pack8(acc);
+    }
+}
+extern "C" int pk_fuse_sum(const void* const* inputs, const int* in_h, const int* in_w, int n_inputs, void* out, int B, int H, int W,
+                           int C, int relu, void* stream) {
+    PK_REQUIRE(inputs && in_h && in_w && out && n_inputs >= 1 && n_inputs <= 4, "pk_fuse_sum: bad argument");
+    PK_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0 && (C & 7) == 0, "pk_fuse_sum: bad shape");
+    FuseArgs a{};
+    for (int i = 0; i < n_inputs; ++i) {
+        PK_REQUIRE(inputs[i] && in_h[i] > 0 && in_w[i] > 0 && in_h[i] <= H && in_w[i] <= W, "pk_fuse_sum: input %d shape", i);
+        a.in[i] = FuseIn{(const uint16_t*)inputs[i], in_h[i], in_w[i]};
+    }
+    a.n = n_inputs; a.out = (uint16_t*)out; a.B = B; a.H = H; a.W = W; a.C = C; a.relu = relu;
+    const size_t chunks = (size_t)B * H * W * (C / 8);
+    size_t gb = (chunks + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_fuse_sum, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, a);
+    return pk_launch_status("pk_fuse_sum");
+}
+
+// Backward of the bilinear up-sampling (gather form, deterministic): dsrc[b][ys][xs][c] = sum over the output pixels
+// whose taps touch (ys,xs) of weight * dy.  `dy` is the (already relu-masked) gradient at the fused resolution.
+__global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dsrc, int B, int H, int W,
+                                                      int Hs, int Ws, int C) {
+    const int cchunks = C / 8;
+    const size_t chunks = (size_t)B * Hs * Ws * cchunks;
+    const int ry = (H + Hs - 1) / Hs, rx = (W + Ws - 1) / Ws;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % cchunks);
+        size_t pix = i / cchunks;
+        const int xs = (int)(pix % Ws);
+        pix /= Ws;
+        const int ys = (int)(pix % Hs), b = (int)(pix / Hs);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const int oy_lo = max(0, (ys - 1) * ry - ry), oy_hi = min(H, (ys + 2) * ry + ry);
+        const int ox_lo = max(0, (xs - 1) * rx - rx), ox_hi = min(W, (xs + 2) * rx + rx);
+        for (int oy = oy_lo; oy < oy_hi; ++oy) {
+            int y0, y1;
+            float fy;
+            bil_taps(oy, Hs, H, y0, y1, fy);
+            const float wy = (y0 == ys ? 1.f - fy : 0.f) + (y1 == ys ? fy : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = ox_lo; ox < ox_hi; ++ox) {
+                int x0, x1;
+                float fx;
+                bil_taps(ox, Ws, W, x0, x1, fx);
+                const float wx = (x0 == xs ? 1.f - fx : 0.f) + (x1 == xs ? fx : 0.f);
+                if (wx == 0.f) continue;
+                float v[8];
+                unpack8(*reinterpret_cast<const uint4*>(dy + (((size_t)b * H + oy) * W + ox) * C + cc * 8), v);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += wy * wx * v[j];
+            }
+        }
+        *reinterpret_cast<uint4*>(dsrc + i * 8) = pack8(acc);
+    }
+}
+extern "C" int pk_upsample_bilinear_bwd(const void* dy, void* dsrc, int B, int H, int W, int Hs, int Ws, int C, void* stream) {
+    PK_REQUIRE(dy && dsrc && B > 0 && H >= Hs && W >= Ws && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0, "pk_upsample_bilinear_bwd: bad argument");
+    const size_t chunks = (size_t)B * Hs * Ws * (C / 8);
+    size_t gb = (chunks + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_upsample_bwd, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dsrc, B, H, W,
+                       Hs, Ws, C);
+    return pk_launch_status("pk_upsample_bilinear_bwd");
+}
+
+// ================================================================================================ layout / packing
+// (B,3,H,W) fp32 NCHW -> (B,H,W,Cp) bf16 NHWC with channels >= Cin zero-filled (Cp = 8: 16-byte pixels for the stem)
+__global__ void __launch_bounds__(256) k_nchw_to_nhwc(const float* __restrict__ x, uint16_t* __restrict__ y, int B, int Cin, int H, int W,
+                                                      int Cp, const float* __restrict__ sp_y) {
+    const size_t pixels = (size_t)B * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < pixels; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t b = i / ((size_t)H * W), r = i - b * H * W;
+        for (int c0 = 0; c0 < Cp; c0 += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float t = 0.f;
+                if (c0 + j < Cin) {
+                    const size_t k = (b * Cin + c0 + j) * H * W + r;
+                    t = x[k];
+                    if (sp_y) t *= 1.f - __expf(-sp_y[k]);     // d softplus(z)/dz = sigmoid(z) = 1 - exp(-softplus(z))
+                }
+                v[j] = t;
+            }
+            *reinterpret_cast<uint4*>(y + i * Cp + c0) = pack8(v);
+        }
+    }
+}
+extern "C" int pk_nchw_f32_to_nhwc_bf16(const float* x, const float* softplus_out, void* y, int B, int Cin, int H, int W, int Cpad,
+                                        void* stream) {
+    PK_REQUIRE(x && y && B > 0 && Cin > 0 && H > 0 && W > 0 && Cpad >= Cin && (Cpad & 7) == 0, "pk_nchw_f32_to_nhwc_bf16: bad argument");
+    const size_t pixels = (size_t)B * H * W;
+    size_t gb = (pixels + 255) / 256;
+    if (gb > 4096) gb = 4096;
+    hipLaunchKernelGGL(k_nchw_to_nhwc, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, x, (uint16_t*)y, B, Cin, H, W, Cpad, softplus_out);
+    return pk_launch_status("pk_nchw_f32_to_nhwc_bf16");
+}
+
+// Weight packing fp32 -> bf16 compute copies, table driven (ONE launch for the whole model).
+//   mode 0: dst[n][t][cp]      = src[n][c][t]            conv forward   (OIHW -> [N][T][Cin_pad])
+//   mode 1: dst[c][T-1-t][n]   = src[n][c][t]            conv data-grad (flipped taps, channels swapped), rows padded to Np
+//   mode 2: dst[c][n]          = src[n][c]               linear data-grad (transpose)
+//   (linear forward is mode 0 with T = 1)
+struct PackDesc { const float* src; int64_t dst_off; int N, C, T, mode, Cp, Np; int64_t dst_numel; };
+__global__ void __launch_bounds__(256) k_pack_weights(uint16_t* __restrict__ dst, const PackDesc* __restrict__ desc,
+                                                      const int* __restrict__ blk_desc, const int* __restrict__ blk_first) {
+    const PackDesc d = desc[blk_desc[blockIdx.x]];
+    const float* __restrict__ src = d.src;
+    const int64_t i0 = (int64_t)(blockIdx.x - blk_first[blockIdx.x]) * 1024;
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = i0 + k * 256 + threadIdx.x;
+        if (i >= d.dst_numel) return;
+        float v = 0.f;
+        if (d.mode == 0) {
+            const int c = (int)(i % d.Cp), t = (int)((i / d.Cp) % d.T), n = (int)(i / ((int64_t)d.Cp * d.T));
+            if (c < d.C) v = src[((int64_t)n * d.C + c) * d.T + t];
+        } else if (d.mode == 1) {
+            const int n = (int)(i % d.Np), t = (int)((i / d.Np) % d.T), c = (int)(i / ((int64_t)d.Np * d.T));
+            if (n < d.N) v = src[((int64_t)n * d.C + c) * d.T + (d.T - 1 - t)];
+        } else {
+            const int n = (int)(i % d.Np), c = (int)(i / d.Np);
+            if (n < d.N) v = src[(int64_t)n * d.C + c];
+        }
+        dst[d.dst_off + i] = f32_to_bf16(v);
+    }
+}
+extern "C" int pk_pack_weights(void* flat_dst_bf16, const void* desc_table, const int32_t* block_desc, const int32_t* block_first,
+                               int n_blocks, void* stream) {
+    PK_REQUIRE(flat_dst_bf16 && desc_table && block_desc && block_first && n_blocks > 0, "pk_pack_weights: bad argument");
+    hipLaunchKernelGGL(k_pack_weights, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, (uint16_t*)flat_dst_bf16,
+                       (const PackDesc*)desc_table, block_desc, block_first);
+    return pk_launch_status("pk_pack_weights");
+}

@@ -17,7 +17,7 @@ from typing import Dict, List, Optional
 import torch
 import torch.distributed as dist
 
-from . import hipops
+from . import hipops, nnops
 
 
 def is_no_decay(name: str) -> bool:
@@ -117,6 +117,9 @@ class FlatAdamW:
         self.step_dev.add_(1)
         hipops.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.flags, None, self.lr_dev, self.step_dev,
                           self.betas[0], self.betas[1], self.eps, self.weight_decay, grad_scale)
+        wc = getattr(self.model, "_pk_weight_cache", None)
+        if wc is not None:
+            wc.mark_dirty()          # the kernel rewrote the fp32 masters behind torch's back: bf16 copies are stale
 
     # -- checkpoint format of the reference (train.py:351-357): per-parameter state keyed by index ---------------
     def state_dict(self):

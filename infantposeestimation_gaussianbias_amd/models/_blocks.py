@@ -7,7 +7,7 @@ called).  All compute goes through `nnops` on NHWC-in-memory bf16 maps.
 import torch
 import torch.nn as nn
 
-from .. import nnops
+from .. import dispatch as nnops
 
 
 def conv(cin, cout, k, stride=1, bias=False):

@@ -10,7 +10,8 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .. import hipops, nnops
+from .. import hipops
+from .. import dispatch as nnops
 from ._blocks import conv
 
 
@@ -65,9 +66,12 @@ class HeatmapRegressionHead(nn.Module):
                     nn.init.zeros_(m.bias)
 
     def forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
+        with nnops.scope(self):
+            return self._forward(x)
+
+    def _forward(self, x: torch.Tensor) -> Dict[str, torch.Tensor]:
         tr = self.training
-        if x.dtype != nnops.ACT_DTYPE:
-            x = nnops.to_features(x)
+        x = nnops.from_public(x)
         s = self.shared_layers
         f = nnops.conv_bn_act(x, s["0"], s["1"], True, None, tr)
         f = nnops.conv_bn_act(f, s["3"], s["4"], True, None, tr)

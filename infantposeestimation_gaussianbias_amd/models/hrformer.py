@@ -10,7 +10,7 @@ from typing import Sequence
 import torch
 import torch.nn as nn
 
-from .. import nnops
+from .. import dispatch as nnops
 from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, make_transition, run_transition
 
 
@@ -108,6 +108,10 @@ class HRFormer(nn.Module):
         init_backbone_weights(self)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        with nnops.scope(self):
+            return nnops.to_public(self._forward(x))
+
+    def _forward(self, x: torch.Tensor) -> torch.Tensor:
         tr = self.training
         x = nnops.to_features(x)
         x = nnops.conv_bn_act(x, self.conv1, self.bn1, True, None, tr)

@@ -4,7 +4,8 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from .. import hipops, nnops
+from .. import hipops
+from .. import dispatch as nnops
 from .fusion_head import FusionPoseLoss, HeatmapRegressionHead, SoftArgmax2D
 from .hrformer import hrformer_base, hrformer_small
 from .hrnet import hrnet_w18, hrnet_w32, hrnet_w48
@@ -28,9 +29,8 @@ class HeatmapHead(nn.Module):
         nn.init.zeros_(self.final_layer.bias)
 
     def forward(self, x):
-        if x.dtype != nnops.ACT_DTYPE:
-            x = nnops.to_features(x)
-        return nnops.head_out(x, self.final_layer)
+        with nnops.scope(self):
+            return nnops.head_out(nnops.from_public(x), self.final_layer)
 
 
 class KeypointMSELoss(nn.Module):
@@ -63,8 +63,9 @@ class PoseEstimator(nn.Module):
         self.soft_argmax = SoftArgmax2D()
 
     def forward(self, x, target=None, target_weight=None, gt_keypoints=None, input_size: Tuple[int, int] = (192, 256)) -> Dict[str, torch.Tensor]:
-        feats = self.backbone(x)
-        output = dict(self.head(feats)) if self.head_type == "fusion" else {"heatmaps": self.head(feats)}
+        with nnops.scope(self):
+            feats = self.backbone(x)
+            output = dict(self.head(feats)) if self.head_type == "fusion" else {"heatmaps": self.head(feats)}
         if target is not None:
             if self.head_type == "fusion" and self.use_fusion_loss and gt_keypoints is not None:
                 H, W = output["heatmaps"].shape[2:]

@@ -1,110 +1,520 @@
-"""Network op layer used by models/*: every op takes/returns PHYSICALLY-NHWC bf16 feature maps.
+"""Network op layer: every dense op of HRFormer / HRNet / the heads as hand-written HIP kernels (libposekernels.so).
 
-Feature maps travel as torch tensors with logical shape (B,C,H,W) in `channels_last` memory format, i.e. the
-bytes in HBM are NHWC; `x.permute(0,2,3,1)` is the free (B,H,W,C) view the HIP kernels index.
+Feature maps are plain contiguous (B,H,W,C) bf16 tensors (NHWC).  Each op is a `torch.autograd.Function` whose
+forward and backward are explicit sequences of C-ABI calls; torch only allocates the tensors and routes gradients.
 
-`IMPL` records, per op, whether it runs as a hand-written HIP kernel ("hip") or is still an ATen composite
-("aten": MIOpen/hipBLASLt/elementwise kernels dispatched by PyTorch-ROCm).  bench.py prints this table with
-every result so a number is never mistaken for an all-HIP path.  ATen entries are stop-gaps to be replaced row
-by row; none of them is a CPU fallback and none touches oracle/.
+  conv_bn_act   A5/A6/H1  conv3x3|1x1 (MFMA implicit GEMM, BN statistics in the epilogue) -> BN finalize -> scale/shift(+res)(+ReLU)
+  head_out      H1/H2     1x1 conv + bias (+softplus) -> fp32 NCHW maps
+  attn_half     A1-A3     LN1 -> qkv GEMM (window gather) -> window attention -> proj GEMM (+residual, DropPath, window scatter)
+  mlp_half      A3        LN2 -> fc1 GEMM + GELU -> fc2 GEMM (+residual, DropPath)
+  fuse_sum      A4        sum of branches with fused bilinear up-sampling (+ReLU)
+
+Shapes the kernels do not cover (channel counts that are not multiples of 8, head_dim > 32: HRFormer-base C=78/d=39,
+HRNet-W18) run on `nnops_aten` (PyTorch-ROCm composites) instead; `backend_for(model)` decides per model and
+`IMPL` reports it.  Neither path is a CPU fallback and neither touches oracle/.
 """
+import numpy as np
 import torch
-import torch.nn.functional as F
 
-IMPL = {
-    "conv_bn_act": "aten",        # A5/A6/H1: 3x3 / 1x1 conv + BatchNorm (+residual) (+ReLU)
-    "window_block": "aten",       # A1-A3: LN1 + window MSA + residual + LN2 + MLP + residual
-    "exchange": "aten",           # A4: 1x1conv+BN+bilinear-up / strided 3x3 chains, sum, ReLU
-    "head_out": "aten",           # H1/H2: final 1x1 conv with bias (+softplus) -> fp32 NCHW
-}
+from . import _lib
+from ._lib import call, stream_ptr
 
-ACT_DTYPE = torch.bfloat16
+BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
+ACT_DTYPE = BF16
 WS = 7
+IMPL = {"conv_bn_act": "hip", "window_block": "hip", "exchange": "hip", "head_out": "hip"}
 
 
-def to_features(x_nchw_f32):
-    """Model input (B,3,H,W) fp32 NCHW -> bf16 NHWC-in-memory."""
-    return x_nchw_f32.to(ACT_DTYPE).contiguous(memory_format=torch.channels_last)
+def _e(shape, dtype, dev):
+    return torch.empty(shape, dtype=dtype, device=dev)
 
 
-def _bn(y, bn, training):
-    if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
-    return F.batch_norm(y, bn.running_mean, bn.running_var, bn.weight, bn.bias, training, 0.1, 1e-5)
+def _up8(n):
+    return -(-n // 8) * 8
 
 
-def conv_bn_act(x, conv, bn=None, relu=False, residual=None, training=False):
-    y = F.conv2d(x, conv.weight.to(ACT_DTYPE), None, conv.stride, conv.padding)
-    if bn is not None:
-        y = _bn(y, bn, training)
-    if residual is not None:
-        y = y + residual
-    return F.relu(y) if relu else y
+# ================================================================================================ weight cache
+_PACK_DTYPE = np.dtype([("src", "<i8"), ("dst_off", "<i8"), ("N", "<i4"), ("C", "<i4"), ("T", "<i4"), ("mode", "<i4"),
+                        ("Cp", "<i4"), ("Np", "<i4"), ("dst_numel", "<i8")])
+
+
+class WeightCache:
+    """bf16 compute copies of every conv / linear weight of a model, refreshed by ONE pk_pack_weights launch.
+
+    Per weight: `fwd` = [N][T][Cin_pad] (forward + wgrad layout) and `dgrad` = conv: [Cin][T flipped][N_pad], linear:
+    [Cin][N_pad] (the data-gradient is the same implicit GEMM with these as its weights).  The fp32 parameters stay the
+    masters in the reference's layouts; call `mark_dirty()` after anything that rewrites them behind torch's back
+    (the fused optimiser kernel); in-place torch writes are caught through `_version`."""
+
+    def __init__(self, model):
+        self.entries = []          # (param, N, C, T)
+        seen = set()
+        for m in model.modules():
+            if isinstance(m, (torch.nn.Conv2d, torch.nn.Linear)) and id(m.weight) not in seen:
+                seen.add(id(m.weight))
+                w = m.weight
+                N, C = w.shape[0], w.shape[1]
+                T = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
+                self.entries.append((w, N, C, T))
+        self.fwd, self.dgrad = {}, {}
+        self._sig = None
+        self._dirty = True
+        self.flat = None
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    def _signature(self):
+        return tuple((w.data_ptr(), w._version) for w, _, _, _ in self.entries)
+
+    def _build(self, dev):
+        rows, off = [], 0
+        layout = []
+        for w, N, C, T in self.entries:
+            Cp, Np = _up8(C), _up8(N)
+            n_f = N * T * Cp
+            rows.append((w.data_ptr(), off, N, C, T, 0, Cp, Np, n_f))
+            layout.append(("f", w, off, (N, T, Cp)))
+            off += -(-n_f // 8) * 8
+            n_d = C * T * Np
+            rows.append((w.data_ptr(), off, N, C, T, 1 if T > 1 else 2, Cp, Np, n_d))
+            layout.append(("d", w, off, (C, T, Np)))
+            off += -(-n_d // 8) * 8
+        if self.flat is None or self.flat.numel() != off or self.flat.device != dev:
+            self.flat = torch.empty(off, dtype=BF16, device=dev)
+        desc = np.array(rows, dtype=_PACK_DTYPE)
+        blk_desc, blk_first, nb = [], [], 0
+        for i, r in enumerate(rows):
+            k = -(-r[8] // 1024)
+            blk_desc += [i] * k
+            blk_first += [nb] * k
+            nb += k
+        self._desc = torch.from_numpy(desc.view(np.uint8)).to(dev)
+        self._blk_desc = torch.tensor(blk_desc, dtype=I32, device=dev)
+        self._blk_first = torch.tensor(blk_first, dtype=I32, device=dev)
+        self._nb = nb
+        for kind, w, o, shape in layout:
+            view = self.flat[o:o + shape[0] * shape[1] * shape[2]].view(shape)
+            (self.fwd if kind == "f" else self.dgrad)[id(w)] = view
+
+    def ensure_fresh(self):
+        if not self.entries:
+            return
+        dev = self.entries[0][0].device
+        sig = self._signature()
+        ptrs = tuple(s[0] for s in sig)
+        if self._sig is None or tuple(s[0] for s in self._sig) != ptrs or self.flat is None or self.flat.device != dev:
+            self._build(dev)
+            self._dirty = True
+        if self._dirty or sig != self._sig:
+            call("pk_pack_weights", self.flat, self._desc, self._blk_desc, self._blk_first, self._nb, stream_ptr())
+            self._sig, self._dirty = sig, False
+
+
+def weight_cache(model) -> WeightCache:
+    wc = getattr(model, "_pk_weight_cache", None)
+    if wc is None:
+        wc = WeightCache(model)
+        object.__setattr__(model, "_pk_weight_cache", wc)
+    return wc
+
+
+_CURRENT = []   # stack of active WeightCache objects (set by the model's forward)
+
+
+class use_weights:
+    def __init__(self, model):
+        self.wc = weight_cache(model)
+
+    def __enter__(self):
+        self.wc.ensure_fresh()
+        _CURRENT.append(self.wc)
+        return self.wc
+
+    def __exit__(self, *a):
+        _CURRENT.pop()
+
+
+def _wc():
+    if not _CURRENT:
+        raise _lib.PoseKernelError("nnops: no active weight cache (call the model's forward, or wrap in nnops.use_weights(model))")
+    return _CURRENT[-1]
+
+
+# ================================================================================================ helpers
+def to_features(x_nchw_f32, cpad=8):
+    """(B,Cin,H,W) fp32 NCHW -> (B,H,W,cpad) bf16 NHWC, channels >= Cin zero (16-byte pixels for the stem conv)."""
+    x = x_nchw_f32.float().contiguous()
+    B, Cin, H, W = x.shape
+    y = _e((B, H, W, max(cpad, _up8(Cin))), BF16, x.device)
+    call("pk_nchw_f32_to_nhwc_bf16", x, None, y, B, Cin, H, W, y.shape[-1], stream_ptr())
+    return y
+
+
+def _conv_geometry(x, ksize, stride):
+    B, Hs, Ws, Cin = x.shape
+    pad = ksize // 2
+    return B, Hs, Ws, Cin, (Hs + 2 * pad - ksize) // stride + 1, (Ws + 2 * pad - ksize) // stride + 1
+
+
+def _conv_raw(x, wf, Cout, ksize, stride, stats):
+    B, Hs, Ws, Cin, Ho, Wo = _conv_geometry(x, ksize, stride)
+    raw = _e((B, Ho, Wo, Cout), BF16, x.device)
+    part = None
+    if stats:
+        tiles = _lib.lib.pk_conv_stats_tiles(B * Ho * Wo)
+        part = _e((tiles, 2, Cout), F32, x.device)
+    call("pk_conv2d_nhwc", x, wf, raw, part, None, B, Hs, Ws, Cin, Cout, ksize, stride, 0, Ho, Wo, 0, 0, stream_ptr())
+    return raw, part
+
+
+def _conv_dgrad(g, wd, Cin, ksize, stride, in_hw):
+    """g (B,Ho,Wo,Cout) -> dx (B,Hs,Ws,Cin) with the flipped / transposed weight copy `wd` [Cin][T][Cout_pad]."""
+    B, Ho, Wo, Cout = g.shape
+    Hs, Ws = in_hw
+    dx = _e((B, Hs, Ws, Cin), BF16, g.device)
+    call("pk_conv2d_nhwc", g, wd, dx, None, None, B, Ho, Wo, Cout, Cin, ksize, 1, 1 if stride == 2 else 0, Hs, Ws, 0, 0, stream_ptr())
+    return dx
+
+
+def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=None, g_rps=0, M=None, oihw=True):
+    """-> fp32 gradient (N, Cin, k, k) for conv (geom=(B,Hs,Ws,Ho,Wo)) or (N, Cin) for linear (geom=None)."""
+    T = ksize * ksize
+    if geom is None:
+        B = Hs = Ws = Ho = Wo = 0
+    else:
+        B, Hs, Ws, Ho, Wo = geom
+        M = B * Ho * Wo
+    S = _lib.lib.pk_wgrad_slices(M, N, Cin, T)
+    ws = _e((S * N * T * Cin,), F32, x.device)
+    dw = _e((N, Cin, ksize, ksize) if geom is not None else (N, Cin), F32, x.device)
+    call("pk_wgrad_bf16", x, g, ws, dw, a_map, g_map, g_scale, g_rps, M, N, Cin, ksize, stride, B, Hs, Ws, Ho, Wo,
+         1 if (geom is not None and oihw) else 0, stream_ptr())
+    return dw
+
+
+def _colsum(g, rows, N, rowmap=None, row_scale=None, rps=0):
+    nb = _lib.lib.pk_ln_bwd_blocks(rows)
+    part = _e((nb, N), F32, g.device)
+    out = _e((N,), F32, g.device)
+    call("pk_colsum_bf16", g, rowmap, row_scale, rps, part, out, rows, N, stream_ptr())
+    return out
+
+
+# ================================================================================================ conv + BN (+res) (+ReLU)
+class _ConvBnAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, relu, training):
+        wc = _wc()
+        wf, wd = wc.fwd[id(weight)], wc.dgrad[id(weight)]
+        Cout, Cin_real, ksize = weight.shape[0], weight.shape[1], weight.shape[2]
+        x = x.contiguous()
+        B, Hs, Ws, Cin, Ho, Wo = _conv_geometry(x, ksize, stride)
+        M = B * Ho * Wo
+        dev = x.device
+        raw, part = _conv_raw(x, wf, Cout, ksize, stride, training)
+        scale, shift = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
+        mean, rstd = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
+        if training:
+            call("pk_bn_finalize", part, part.shape[0], Cout, M, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                 0.1, 1e-5, scale, shift, mean, rstd, stream_ptr())
+        else:
+            torch.rsqrt(bn.running_var + 1e-5, out=rstd)
+            torch.mul(gamma, rstd, out=scale)
+            torch.addcmul(beta, bn.running_mean, scale, value=-1.0, out=shift)
+            mean.copy_(bn.running_mean)
+        y = _e(raw.shape, BF16, dev)
+        res = None if residual is None else residual.contiguous()
+        call("pk_bn_act", raw, scale, shift, res, y, M, Cout, 1 if relu else 0, stream_ptr())
+        ctx.save_for_backward(x, raw, y, mean, rstd, gamma, wd)
+        ctx.meta = (stride, relu, training, residual is not None, Cin_real, ksize, (B, Hs, Ws, Ho, Wo))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, raw, y, mean, rstd, gamma, wd = ctx.saved_tensors
+        stride, relu, training, has_res, Cin_real, ksize, (B, Hs, Ws, Ho, Wo) = ctx.meta
+        if not training:
+            raise _lib.PoseKernelError("conv_bn_act: backward through eval-mode BatchNorm is not implemented")
+        dev, Cout, Cin, M = dy.device, raw.shape[-1], x.shape[-1], B * Ho * Wo
+        dy = dy.contiguous()
+        nb = _lib.lib.pk_bn_bwd_blocks(M)
+        part, sums = _e((nb, 2, Cout), F32, dev), _e((2 * Cout,), F32, dev)
+        dgamma, dbeta = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
+        draw = _e(raw.shape, BF16, dev)
+        dres = _e(raw.shape, BF16, dev) if has_res else None
+        call("pk_bn_bwd", dy, y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, dres, M, Cout, 1 if relu else 0, stream_ptr())
+        dx = _conv_dgrad(draw, wd, Cin, ksize, stride, (Hs, Ws)) if ctx.needs_input_grad[0] else None
+        dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo))
+        if Cin != Cin_real:
+            dw = dw[:, :Cin_real].contiguous()
+        return dx, dw, dgamma, dbeta, dres, None, None, None, None
+
+
+def conv_bn_act(x, conv, bn, relu=False, residual=None, training=False):
+    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], relu, training)
+
+
+# ================================================================================================ head output conv
+class _HeadOut(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, softplus):
+        wc = _wc()
+        wf, wd = wc.fwd[id(weight)], wc.dgrad[id(weight)]
+        x = x.contiguous()
+        B, H, W, Cin = x.shape
+        N = weight.shape[0]
+        out = _e((B, N, H, W), F32, x.device)
+        call("pk_conv2d_nhwc", x, wf, out, None, bias, B, H, W, Cin, N, 1, 1, 0, H, W, 2 if softplus else 0, 2, stream_ptr())
+        ctx.save_for_backward(x, out if softplus else x.new_empty(0), wd)
+        ctx.meta = (softplus, N)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, y, wd = ctx.saved_tensors
+        softplus, N = ctx.meta
+        B, H, W, Cin = x.shape
+        Np = _up8(N)
+        g = _e((B, H, W, Np), BF16, x.device)
+        call("pk_nchw_f32_to_nhwc_bf16", dout.contiguous(), y if softplus else None, g, B, N, H, W, Np, stream_ptr())
+        dx = _e((B, H, W, Cin), BF16, x.device)
+        call("pk_conv2d_nhwc", g, wd, dx, None, None, B, H, W, Np, Cin, 1, 1, 0, H, W, 0, 0, stream_ptr())
+        dw = _wgrad(x, g, Np, Cin, 1, 1, (B, H, W, H, W))[:N].contiguous()
+        db = _colsum(g, B * H * W, Np)[:N].contiguous()
+        return dx, dw, db, None
 
 
 def head_out(x, conv, softplus=False):
-    """Final 1x1 conv with bias; fp32 NCHW output (these maps feed the fp32 loss / decoders)."""
-    y = F.conv2d(x, conv.weight.to(ACT_DTYPE), conv.bias.to(ACT_DTYPE)).float().contiguous()
-    return F.softplus(y) if softplus else y
+    return _HeadOut.apply(x, conv.weight, conv.bias, softplus)
 
 
-def rel_bias(attn, heads):
-    n = WS * WS
-    return attn.relative_position_bias_table[attn.relative_position_index.reshape(-1)].reshape(n, n, heads).permute(2, 0, 1)
+# ================================================================================================ HRFormer block halves
+_MAPS = {}
+
+
+def window_rowmap(B, H, W, device):
+    """int32 map: window-order token (b, wy, wx, ty, tx) -> pixel row b*H*W + y*W + x, or -1 for the zero-pad tokens
+    appended at the bottom/right (hrformer.py:80-89).  Built once per shape."""
+    key = (B, H, W, str(device))
+    if key not in _MAPS:
+        nh, nw = -(-H // WS), -(-W // WS)
+        ys = (torch.arange(nh)[:, None] * WS + torch.arange(WS)[None, :])            # (nh, ws)
+        xs = (torch.arange(nw)[:, None] * WS + torch.arange(WS)[None, :])            # (nw, ws)
+        yy = ys[:, None, :, None].expand(nh, nw, WS, WS)
+        xx = xs[None, :, None, :].expand(nh, nw, WS, WS)
+        pix = torch.where((yy < H) & (xx < W), yy * W + xx, torch.full_like(yy, -1)).reshape(-1)
+        full = pix[None, :].repeat(B, 1)
+        full = torch.where(full >= 0, full + torch.arange(B)[:, None] * (H * W), full)
+        _MAPS[key] = (full.reshape(-1).to(torch.int32).to(device), nh * nw)
+    return _MAPS[key]
+
+
+def _layernorm(x2d, gamma, beta):
+    M, C = x2d.shape
+    y = _e((M, C), BF16, x2d.device)
+    mean, rstd = _e((M,), F32, x2d.device), _e((M,), F32, x2d.device)
+    call("pk_layernorm_fwd", x2d, gamma, beta, y, mean, rstd, M, C, 1e-5, stream_ptr())
+    return y, mean, rstd
+
+
+def _layernorm_bwd(dy, x2d, mean, rstd, gamma, dres):
+    M, C = x2d.shape
+    nb = _lib.lib.pk_ln_bwd_blocks(M)
+    part = _e((nb, 2, C), F32, x2d.device)
+    dx = _e((M, C), BF16, x2d.device)
+    dg, db = _e((C,), F32, x2d.device), _e((C,), F32, x2d.device)
+    call("pk_layernorm_bwd", dy, x2d, mean, rstd, gamma, dres, dx, part, dg, db, M, C, stream_ptr())
+    return dx, dg, db
+
+
+def _linear(x, w, out_rows, N, K, bias=None, residual=None, res_scale=None, a_map=None, o_map=None, preact=None, gelu_of=None,
+            M=None, rps=0, act=0):
+    out = _e((out_rows, N), BF16, x.device)
+    call("pk_linear_bf16", x, w, out, bias, residual, res_scale, a_map, o_map, preact, gelu_of, M if M is not None else out_rows, N, K,
+         rps, act, 0, stream_ptr())
+    return out
+
+
+class _AttnHalf(torch.autograd.Function):
+    """x + s1 * proj(window_attention(qkv(LN1(x))))   on (B,H,W,C) bf16."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, table, wqkv, bqkv, wproj, bproj, scale1, heads):
+        wc = _wc()
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        M = B * H * W
+        amap, nwin = window_rowmap(B, H, W, x.device)
+        Mw = B * nwin * WS * WS
+        x2 = x.view(M, C)
+        u, mean, rstd = _layernorm(x2, g1, b1)
+        qkv = _linear(u, wc.fwd[id(wqkv)], Mw, 3 * C, C, bias=bqkv, a_map=amap)
+        o = _e((Mw, C), BF16, x.device)
+        lse = _e((B * nwin * heads * WS * WS,), F32, x.device)
+        call("pk_window_attn_fwd", qkv, table, o, lse, B * nwin, heads, C, stream_ptr())
+        s1 = None if scale1 is None else scale1.float().contiguous()
+        y = _linear(o, wc.fwd[id(wproj)], M, C, C, bias=bproj, residual=x2, res_scale=s1, o_map=amap, M=Mw, rps=H * W)
+        ctx.save_for_backward(x2, u, mean, rstd, qkv, o, lse, g1, table, s1 if s1 is not None else x.new_empty(0),
+                              wc.dgrad[id(wqkv)], wc.dgrad[id(wproj)], amap)
+        ctx.meta = (B, H, W, C, heads, nwin, s1 is not None)
+        return y.view(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, u, mean, rstd, qkv, o, lse, g1, table, s1, wqkv_t, wproj_t, amap = ctx.saved_tensors
+        B, H, W, C, heads, nwin, has_s = ctx.meta
+        s1 = s1 if has_s else None
+        M, Mw = B * H * W, B * nwin * WS * WS
+        dev = dy.device
+        dy2 = dy.contiguous().view(M, C)
+        # proj: rows of the GEMM are window-order tokens, dy rows are gathered through the map; DropPath scale per sample
+        d_o = _linear(dy2, wproj_t, Mw, C, C, res_scale=s1, a_map=amap, rps=nwin * WS * WS)
+        dwproj = _wgrad(o, dy2, C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw)
+        dbproj = _colsum(dy2, M, C, row_scale=s1, rps=H * W)
+        # attention core
+        dqkv = _e((Mw, 3 * C), BF16, dev)
+        part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads),), F32, dev)
+        dtable = _e(tuple(table.shape), F32, dev)
+        call("pk_window_attn_bwd", qkv, table, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, stream_ptr())
+        # qkv linear: scatter the token gradients back to pixel rows (pad tokens dropped)
+        du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
+        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw)
+        dbqkv = _colsum(dqkv, Mw, 3 * C)
+        dx, dg1, db1 = _layernorm_bwd(du, x2, mean, rstd, g1, dy2)
+        return dx.view(B, H, W, C), dg1, db1, dtable, dwqkv, dbqkv, dwproj, dbproj, None, None
+
+
+class _MlpHalf(torch.autograd.Function):
+    """x + s2 * fc2(gelu(fc1(LN2(x))))   on (B,H,W,C) bf16."""
+
+    @staticmethod
+    def forward(ctx, x, g2, b2, w1, bias1, w2, bias2, scale2):
+        wc = _wc()
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        M, Hd = B * H * W, w1.shape[0]
+        x2 = x.view(M, C)
+        v, mean, rstd = _layernorm(x2, g2, b2)
+        z = _e((M, Hd), BF16, x.device)
+        h = _linear(v, wc.fwd[id(w1)], M, Hd, C, bias=bias1, preact=z, act=1)
+        s2 = None if scale2 is None else scale2.float().contiguous()
+        y = _linear(h, wc.fwd[id(w2)], M, C, Hd, bias=bias2, residual=x2, res_scale=s2, rps=H * W)
+        ctx.save_for_backward(x2, v, mean, rstd, z, h, g2, s2 if s2 is not None else x.new_empty(0), wc.dgrad[id(w1)], wc.dgrad[id(w2)])
+        ctx.meta = (B, H, W, C, Hd, s2 is not None)
+        return y.view(B, H, W, C)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, v, mean, rstd, z, h, g2, s2, w1_t, w2_t = ctx.saved_tensors
+        B, H, W, C, Hd, has_s = ctx.meta
+        s2 = s2 if has_s else None
+        M = B * H * W
+        dy2 = dy.contiguous().view(M, C)
+        dz = _linear(dy2, w2_t, M, Hd, C, res_scale=s2, gelu_of=z, rps=H * W)        # (dy W2) * s2 * gelu'(z)
+        dw2 = _wgrad(h, dy2, C, Hd, 1, 1, None, g_scale=s2, g_rps=H * W, M=M)
+        db2 = _colsum(dy2, M, C, row_scale=s2, rps=H * W)
+        dv = _linear(dz, w1_t, M, C, Hd)
+        dw1 = _wgrad(v, dz, Hd, C, 1, 1, None, M=M)
+        db1 = _colsum(dz, M, Hd)
+        dx, dg2, dbt2 = _layernorm_bwd(dv, x2, mean, rstd, g2, dy2)
+        return dx.view(B, H, W, C), dg2, dbt2, dw1, db1, dw2, db2, None
 
 
 def window_block(x, blk, heads, scale1=None, scale2=None):
-    """One HRFormer block on a (B,C,H,W) channels_last bf16 map. scale*: per-sample DropPath multipliers (B,) or None."""
-    B, C, H, W = x.shape
-    t = x.permute(0, 2, 3, 1)                                   # (B,H,W,C) view
-    u = F.layer_norm(t.float(), (C,), blk.norm1.weight, blk.norm1.bias, 1e-5).to(ACT_DTYPE)
-    Hp, Wp = -(-H // WS) * WS, -(-W // WS) * WS
-    u = F.pad(u, (0, 0, 0, Wp - W, 0, Hp - H))                  # zero tokens AFTER LN1, no mask (reference semantics)
-    nh, nw = Hp // WS, Wp // WS
-    tok = u.reshape(B, nh, WS, nw, WS, C).permute(0, 1, 3, 2, 4, 5).reshape(B * nh * nw, WS * WS, C)
     a = blk.attn
-    d = C // heads
-    qkv = F.linear(tok, a.qkv.weight.to(ACT_DTYPE), a.qkv.bias.to(ACT_DTYPE)).reshape(-1, WS * WS, 3, heads, d).permute(2, 0, 3, 1, 4)
-    bias = rel_bias(a, heads).to(ACT_DTYPE).unsqueeze(0)
-    o = F.scaled_dot_product_attention(qkv[0], qkv[1], qkv[2], attn_mask=bias, scale=d ** -0.5)
-    o = o.transpose(1, 2).reshape(-1, WS * WS, C)
-    o = F.linear(o, a.proj.weight.to(ACT_DTYPE), a.proj.bias.to(ACT_DTYPE))
-    o = o.reshape(B, nh, nw, WS, WS, C).permute(0, 1, 3, 2, 4, 5).reshape(B, Hp, Wp, C)[:, :H, :W]
-    if scale1 is not None:
-        o = o * scale1.view(B, 1, 1, 1).to(ACT_DTYPE)
-    t = t + o
-    v = F.layer_norm(t.float(), (C,), blk.norm2.weight, blk.norm2.bias, 1e-5).to(ACT_DTYPE)
-    m = F.linear(F.gelu(F.linear(v, blk.mlp.fc1.weight.to(ACT_DTYPE), blk.mlp.fc1.bias.to(ACT_DTYPE))),
-                 blk.mlp.fc2.weight.to(ACT_DTYPE), blk.mlp.fc2.bias.to(ACT_DTYPE))
-    if scale2 is not None:
-        m = m * scale2.view(B, 1, 1, 1).to(ACT_DTYPE)
-    return (t + m).permute(0, 3, 1, 2)                          # logical NCHW, still NHWC in memory
+    x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+                        a.proj.weight, a.proj.bias, scale1, heads)
+    m = blk.mlp
+    return _MlpHalf.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2)
+
+
+# ================================================================================================ exchange unit
+class _FuseSum(torch.autograd.Function):
+    """relu(sum_i up(x_i)) with bilinear (align_corners=False) up-sampling of the lower-resolution inputs fused in."""
+
+    @staticmethod
+    def forward(ctx, relu, *xs):
+        xs = [t.contiguous() for t in xs]
+        ref = max(xs, key=lambda t: t.shape[1] * t.shape[2])
+        B, H, W, C = ref.shape
+        dev = ref.device
+        ptrs = torch.tensor([t.data_ptr() for t in xs], dtype=torch.int64)
+        hs = torch.tensor([t.shape[1] for t in xs], dtype=torch.int32)
+        wsz = torch.tensor([t.shape[2] for t in xs], dtype=torch.int32)
+        out = _e((B, H, W, C), BF16, dev)
+        # host arrays: the C-ABI reads them before the launch returns (pointer table is copied into the kernel arguments)
+        call("pk_fuse_sum", ptrs.data_ptr(), hs.data_ptr(), wsz.data_ptr(), len(xs), out, B, H, W, C, 1 if relu else 0, stream_ptr())
+        ctx.save_for_backward(out)
+        ctx.meta = (relu, [tuple(t.shape) for t in xs])
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (out,) = ctx.saved_tensors
+        relu, shapes = ctx.meta
+        B, H, W, C = out.shape
+        dy = dy.contiguous()
+        g = dy
+        if relu:
+            g = _e(out.shape, BF16, out.device)
+            call("pk_relu_bwd", dy, out, g, out.numel(), stream_ptr())
+        grads = []
+        for shp in shapes:
+            if shp[1] == H and shp[2] == W:
+                grads.append(g)
+            else:
+                d = _e(shp, BF16, out.device)
+                call("pk_upsample_bilinear_bwd", g, d, B, H, W, shp[1], shp[2], C, stream_ptr())
+                grads.append(d)
+        return (None, *grads)
+
+
+def fuse_sum(xs, relu=True):
+    return _FuseSum.apply(relu, *xs)
 
 
 def exchange(xs, fuse, training, n_out=None):
-    """Exchange unit: out_i = relu(sum_j route_{j->i}(x_j)), j ascending (hrformer.py:462-491 == hrnet.py:198-227)."""
+    """Exchange unit (hrformer.py:462-491 == hrnet.py:198-227): out_i = relu(sum_j route_{j->i}(x_j))."""
     n = len(xs)
     outs = []
     for i in range(n if n_out is None else n_out):
-        acc = None
+        terms = []
         for j in range(n):
             if j == i:
-                t = xs[j]
+                terms.append(xs[j])
             elif j > i:
                 conv, bn = fuse[str(i)][str(j)]
-                t = conv_bn_act(xs[j], conv, bn, False, None, training)
-                t = F.interpolate(t, size=xs[i].shape[-2:], mode="bilinear", align_corners=False)
+                terms.append(conv_bn_act(xs[j], conv, bn, False, None, training))      # up-sampled inside fuse_sum
             else:
                 t = xs[j]
                 chain = fuse[str(i)][str(j)]
                 for s, (conv, bn) in enumerate(chain):
                     t = conv_bn_act(t, conv, bn, s != len(chain) - 1, None, training)
-            acc = t if acc is None else acc + t
-        outs.append(F.relu(acc))
+                terms.append(t)
+        outs.append(fuse_sum(terms, True))
     return outs
 
 
 def drop_scales(n_draws, batch, drop_prob, device):
-    """All DropPath multipliers of one step in one launch: floor(keep + U)/keep, shape (n_draws, B)."""
+    """All DropPath multipliers of one step in one launch: floor(keep + U)/keep, shape (n_draws, B) (hrformer.py:15-24)."""
     keep = 1.0 - drop_prob
     return torch.floor(keep + torch.rand(n_draws, batch, device=device)) / keep
+
+
+# ================================================================================================ backend choice
+def supported(model) -> bool:
+    """True when every conv / linear of `model` fits the HIP kernels (channels % 8 == 0, head_dim in {8,16,24,32})."""
+    for m in model.modules():
+        if isinstance(m, torch.nn.Conv2d):
+            if m.weight.shape[0] % 8 and m.weight.shape[2] != 1:
+                return False
+            if m.weight.shape[1] % 8 and m.weight.shape[1] != 3:
+                return False
+        if hasattr(m, "relative_position_bias_table"):
+            d = m.qkv.weight.shape[1] // m.relative_position_bias_table.shape[1]
+            if d > 32 or d % 8:
+                return False
+        if isinstance(m, torch.nn.LayerNorm) and m.normalized_shape[0] % 8:
+            return False
+    return True

@@ -1,0 +1,452 @@
+"""GPU parity tests (`-m gpu`) of the network kernels (bf16 MFMA contractions, BN/LN, attention, exchange unit).
+
+Inputs and weights are made bf16-representable, the reference is plain PyTorch fp32 on the CPU (or the oracle in
+oracle/nets.py), so the only differences are fp32 accumulation order and the final bf16 rounding of stored outputs:
+tolerance 2e-3 norm-wise where the kernel emits fp32, 8e-3 (= 2 bf16 ulp) where it stores bf16, stated per test.
+"""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+from recipe import synth_input, synth_state_dict
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+BF = torch.bfloat16
+
+
+def q(t):
+    """round to bf16-representable fp32"""
+    return t.to(BF).float()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return q(torch.randn(*shape, generator=g) * scale)
+
+
+def C(t):
+    return t.detach().float().cpu()
+
+
+def nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous().to(DEV, BF)
+
+
+def nchw(x_nhwc):
+    return C(x_nhwc).permute(0, 3, 1, 2)
+
+
+def err(a, b):
+    return rel_err(C(a).numpy() if isinstance(a, torch.Tensor) else a, C(b).numpy() if isinstance(b, torch.Tensor) else b)
+
+
+def err2(a, b):
+    """relative L2 error: robust to the isolated O(1) element changes a flipped ReLU mask causes"""
+    a, b = C(a).double().reshape(-1), C(b).double().reshape(-1)
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+@pytest.fixture(scope="module")
+def N():
+    from infantposeestimation_gaussianbias_amd import nnops
+    return nnops
+
+
+class Holder(torch.nn.Module):
+    def __init__(self, **mods):
+        super().__init__()
+        for k, v in mods.items():
+            setattr(self, k, v)
+
+
+# ------------------------------------------------------------------------------------------------ conv kernel
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", [(2, 9, 7, 16, 24, 3, 1), (2, 10, 6, 8, 16, 3, 2), (1, 5, 5, 32, 40, 1, 1),
+                                                (3, 11, 13, 40, 136, 3, 1), (2, 7, 9, 24, 32, 3, 2), (4, 64, 48, 32, 256, 3, 1),
+                                                (1, 16, 12, 256, 128, 3, 1), (2, 8, 6, 64, 32, 1, 1)])
+def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
+    from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
+    conv = torch.nn.Conv2d(Cin, Cout, k, s, k // 2, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight * 3))
+    x = rnd(B, Cin, H, W, seed=1)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(xr, conv.weight, None, s, k // 2)
+    gy = rnd(*ref.shape, seed=2)
+    ref.backward(gy)
+    import copy
+    m = Holder(c=copy.deepcopy(conv)).to(DEV)
+    with N.use_weights(m) as wc:
+        wf, wd = wc.fwd[id(m.c.weight)], wc.dgrad[id(m.c.weight)]
+        xd = nhwc(x)
+        Ho, Wo = ref.shape[2:]
+        out = torch.empty(B, Ho, Wo, Cout, device=DEV)
+        tiles = lib.pk_conv_stats_tiles(B * Ho * Wo)
+        part = torch.empty(tiles, 2, Cout, device=DEV)
+        call("pk_conv2d_nhwc", xd, wf, out, part, None, B, H, W, Cin, Cout, k, s, 0, Ho, Wo, 0, 1, stream_ptr())
+        assert err(nchw(out), ref.detach()) < 2e-3                                   # fp32 output: accumulation order only
+        st = C(part).sum(0)
+        assert err(st[0], ref.detach().sum((0, 2, 3))) < 2e-3
+        assert err(st[1], (ref.detach() ** 2).sum((0, 2, 3))) < 2e-3
+        raw, _ = N._conv_raw(xd, wf, Cout, k, s, False)
+        assert err(nchw(raw), ref.detach()) < 8e-3                                   # bf16 store
+        dx = N._conv_dgrad(nhwc(gy), wd, Cin, k, s, (H, W))
+        assert err(nchw(dx), xr.grad) < 8e-3
+        dw = N._wgrad(xd, nhwc(gy), Cout, Cin, k, s, (B, H, W, Ho, Wo))
+        assert err(C(dw), conv.weight.grad) < 2e-3
+
+
+def test_stem_conv_padded_input_and_head_out(N):
+    """3-channel NCHW fp32 input -> NHWC bf16 padded to 8 channels -> 3x3 s2 conv; 1x1 head conv with bias/softplus to NCHW fp32."""
+    conv = torch.nn.Conv2d(3, 64, 3, 2, 1, bias=False)
+    bn = torch.nn.BatchNorm2d(64)
+    head = torch.nn.Conv2d(64, 17, 1)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight))
+        head.weight.copy_(q(head.weight * 4))
+        head.bias.copy_(torch.randn(17) * 0.3)
+    x = rnd(2, 3, 16, 12, seed=3)
+    xr = x.clone()
+    y_ref = F.relu(F.batch_norm(F.conv2d(xr, conv.weight, None, 2, 1), None, None, bn.weight, bn.bias, True, 0.1, 1e-5))
+    for sp in (False, True):
+        yq = q(y_ref.detach()).requires_grad_(True)
+        o_ref = F.conv2d(yq, head.weight, head.bias)
+        o_ref = F.softplus(o_ref) if sp else o_ref
+        go = torch.randn(o_ref.shape, generator=torch.Generator().manual_seed(4))
+        head.zero_grad()
+        o_ref.backward(go)
+        import copy
+        m = Holder(c=copy.deepcopy(conv), b=copy.deepcopy(bn), h=copy.deepcopy(head)).to(DEV).train()
+        with N.use_weights(m):
+            f = N.to_features(x.to(DEV))
+            assert f.shape == (2, 16, 12, 8) and float(f[..., 3:].abs().max()) == 0
+            y = N.conv_bn_act(f, m.c, m.b, True, None, True)
+            assert err(nchw(y), y_ref.detach()) < 1e-2
+            yd = nhwc(yq.detach()).requires_grad_(True)
+            o = N.head_out(yd, m.h, sp)
+            assert o.shape == (2, 17, 8, 6) and o.dtype == torch.float32
+            assert err(C(o), o_ref.detach()) < 2e-3
+            o.backward(go.to(DEV))
+            assert err(nchw(yd.grad), yq.grad) < 1e-2                              # dY was rounded to bf16 on the way in
+            assert err(C(m.h.weight.grad), head.weight.grad) < 1e-2
+            assert err(C(m.h.bias.grad), head.bias.grad) < 1e-2
+
+
+@pytest.mark.parametrize("train", [True, False])
+@pytest.mark.parametrize("relu,res", [(True, False), (True, True), (False, False)])
+def test_conv_bn_act_function(N, train, relu, res):
+    from oracle import nets as onet
+    torch.manual_seed(5)
+    conv, bn = torch.nn.Conv2d(16, 32, 3, 1, 1, bias=False), torch.nn.BatchNorm2d(32)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight * 2))
+        bn.weight.copy_(torch.rand(32) + 0.5)
+        bn.bias.copy_(torch.randn(32) * 0.2)
+        bn.running_mean.copy_(torch.randn(32) * 0.1)
+        bn.running_var.copy_(torch.rand(32) + 0.5)
+    x, r = rnd(3, 16, 10, 8, seed=6), rnd(3, 32, 10, 8, seed=7)
+    P = {"c.weight": conv.weight.detach().clone().requires_grad_(True), "b.weight": bn.weight.detach().clone().requires_grad_(True),
+         "b.bias": bn.bias.detach().clone().requires_grad_(True), "b.running_mean": bn.running_mean.clone(), "b.running_var": bn.running_var.clone(),
+         "b.num_batches_tracked": torch.zeros((), dtype=torch.int64)}
+    ctx = onet.Ctx(train=train)
+    xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    y_ref = onet.batchnorm(onet.conv(xr, P, "c"), P, "b", ctx)
+    if res:
+        y_ref = y_ref + rr
+    y_ref = torch.relu(y_ref) if relu else y_ref
+    gy = rnd(*y_ref.shape, seed=8)
+    import copy
+    m = Holder(c=copy.deepcopy(conv), b=copy.deepcopy(bn)).to(DEV).train(train)
+    with N.use_weights(m):
+        xd, rd = nhwc(x).requires_grad_(True), nhwc(r).requires_grad_(True)
+        y = N.conv_bn_act(xd, m.c, m.b, relu, rd if res else None, train)
+        assert err(nchw(y), y_ref.detach()) < 1e-2
+        if not train:
+            return
+        y_ref.backward(gy)
+        y.backward(nhwc(gy))
+        # with ReLU the mask is taken from the bf16-stored output: a handful of near-zero elements flip relative to fp32,
+        # each an O(1) change of its gradient -> looser norm-wise bound than the mask-free case
+        # (L2 for the ReLU cases: isolated flipped elements dominate the max-norm)
+        assert (err2 if relu else err)(nchw(xd.grad), xr.grad) < 3e-2
+        if res:
+            assert (err2 if relu else err)(nchw(rd.grad), rr.grad) < 3e-2
+        assert err(C(m.c.weight.grad), P["c.weight"].grad) < 3e-2
+        assert err(C(m.b.weight.grad), P["b.weight"].grad) < 3e-2
+        assert err(C(m.b.bias.grad), P["b.bias"].grad) < 3e-2
+        onet.apply_bn_updates(P, ctx)
+        assert err(C(m.b.running_mean), P["b.running_mean"]) < 5e-3
+        assert err(C(m.b.running_var), P["b.running_var"]) < 5e-3
+        assert int(m.b.num_batches_tracked) == 1
+
+
+# ------------------------------------------------------------------------------------------------ LayerNorm / linear
+@pytest.mark.parametrize("C_", [32, 64, 128, 256, 24, 16, 8])
+def test_layernorm_fwd_bwd(N, C_):
+    M = 37 * 13
+    x, g, b = rnd(M, C_, seed=1, scale=2.0), torch.rand(C_) + 0.5, torch.randn(C_) * 0.1
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (C_,), gr, br, 1e-5)
+    gy, dres = rnd(M, C_, seed=2), rnd(M, C_, seed=3)
+    y_ref.backward(gy)
+    y, mean, rstd = N._layernorm(x.to(DEV, BF), g.to(DEV), b.to(DEV))
+    assert err(C(y), y_ref.detach()) < 8e-3
+    dx, dg, db = N._layernorm_bwd(gy.to(DEV, BF), x.to(DEV, BF), mean, rstd, g.to(DEV), dres.to(DEV, BF))
+    assert err(C(dx), xr.grad + dres) < 8e-3
+    assert err(C(dg), gr.grad) < 2e-3 and err(C(db), br.grad) < 2e-3
+
+
+def test_linear_rowmaps_gelu_residual(N):
+    from infantposeestimation_gaussianbias_amd._lib import call, stream_ptr
+    B, H, W, Cc, Nn = 2, 9, 10, 32, 96
+    amap, nwin = N.window_rowmap(B, H, W, DEV)
+    assert nwin == 4 and amap.numel() == B * nwin * 49 and int((amap >= 0).sum()) == B * H * W
+    x, w, bias = rnd(B * H * W, Cc, seed=1), rnd(Nn, Cc, seed=2, scale=0.3), torch.randn(Nn) * 0.2
+    am = amap.cpu().long()
+    gathered = torch.where((am >= 0)[:, None], x[am.clamp(min=0)], torch.zeros(1, Cc))
+    ref = gathered @ w.T + bias
+    out = N._linear(x.to(DEV, BF), w.to(DEV, BF), amap.numel(), Nn, Cc, bias=bias.to(DEV), a_map=amap)
+    assert err(C(out), ref) < 8e-3
+    # GELU + saved pre-activation
+    z = torch.empty(amap.numel(), Nn, device=DEV, dtype=BF)
+    h = N._linear(x.to(DEV, BF), w.to(DEV, BF), amap.numel(), Nn, Cc, bias=bias.to(DEV), a_map=amap, preact=z, act=1)
+    assert err(C(z), ref) < 8e-3 and err(C(h), F.gelu(ref)) < 8e-3
+    # scatter + residual + per-sample scale: out[pixel] = res[pixel] + s[b]*(tok @ w2^T + b2)
+    tok, w2, b2 = rnd(amap.numel(), Nn, seed=3), rnd(Cc, Nn, seed=4, scale=0.2), torch.randn(Cc) * 0.1
+    res, s = rnd(B * H * W, Cc, seed=5), torch.tensor([0.0, 1.0 / 0.9])
+    full = tok @ w2.T + b2
+    ref2 = res.clone()
+    valid = am >= 0
+    ref2[am[valid]] += (s[(am[valid] // (H * W))][:, None] * full[valid])
+    out2 = N._linear(tok.to(DEV, BF), w2.to(DEV, BF), B * H * W, Cc, Nn, bias=b2.to(DEV), residual=res.to(DEV, BF), res_scale=s.to(DEV),
+                     o_map=amap, M=amap.numel(), rps=H * W)
+    assert err(C(out2), ref2) < 8e-3
+    # gelu'(z) epilogue
+    zz = rnd(64, Nn, seed=6)
+    g = N._linear(x[:64].to(DEV, BF), w.to(DEV, BF), 64, Nn, Cc, gelu_of=zz.to(DEV, BF))
+    zr = zz.clone().requires_grad_(True)
+    F.gelu(zr).sum().backward()
+    assert err(C(g), (x[:64] @ w.T) * zr.grad) < 8e-3
+    # linear wgrad with maps and scale, bias column sums
+    gout = rnd(B * H * W, Cc, seed=7)
+    dw = N._wgrad(tok.to(DEV, BF), gout.to(DEV, BF), Cc, Nn, 1, 1, None, g_map=amap, g_scale=s.to(DEV), g_rps=H * W, M=amap.numel())
+    gg = torch.zeros(amap.numel(), Cc)
+    gg[valid] = gout[am[valid]] * s[(am[valid] // (H * W))][:, None]
+    assert err(C(dw), gg.T @ tok) < 1e-2          # scaled rows are re-rounded to bf16 inside the kernel
+    db = N._colsum(gout.to(DEV, BF), B * H * W, Cc, row_scale=s.to(DEV), rps=H * W)
+    assert err(C(db), (gout * s.repeat_interleave(H * W)[:, None]).sum(0)) < 2e-3
+
+
+# ------------------------------------------------------------------------------------------------ attention core
+@pytest.mark.parametrize("heads,Cc,nw", [(1, 32, 5), (2, 64, 3), (4, 128, 2), (8, 256, 300), (2, 32, 4)])
+def test_window_attention_core(N, heads, Cc, nw):
+    from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
+    d = Cc // heads
+    qkv = rnd(nw * 49, 3 * Cc, seed=1)
+    table = torch.randn(169, heads, generator=torch.Generator().manual_seed(2)) * 0.5
+    ys, xs = torch.meshgrid(torch.arange(7), torch.arange(7), indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    idx = (ys[:, None] - ys[None, :] + 6) * 13 + (xs[:, None] - xs[None, :] + 6)
+    qr, tr = qkv.clone().requires_grad_(True), table.clone().requires_grad_(True)
+    t = qr.reshape(nw, 49, 3, heads, d)
+    logits = torch.einsum("bnhd,bmhd->bhnm", t[:, :, 0] * d ** -0.5, t[:, :, 1]) + tr[idx.reshape(-1)].reshape(49, 49, heads).permute(2, 0, 1)[None]
+    ref = torch.einsum("bhnm,bmhd->bnhd", torch.softmax(logits, -1), t[:, :, 2]).reshape(nw * 49, Cc)
+    go = rnd(nw * 49, Cc, seed=3)
+    ref.backward(go)
+    o = torch.empty(nw * 49, Cc, device=DEV, dtype=BF)
+    lse = torch.empty(nw * heads * 49, device=DEV)
+    call("pk_window_attn_fwd", qkv.to(DEV, BF), table.to(DEV), o, lse, nw, heads, Cc, stream_ptr())
+    assert err(C(o), ref.detach()) < 1e-2                      # P is rounded to bf16 before the PV product
+    ref_lse = torch.logsumexp(logits.detach(), -1)            # (nw, heads, 49)
+    assert err(C(lse).reshape(nw, heads, 49), ref_lse) < 1e-4
+    dqkv = torch.empty(nw * 49, 3 * Cc, device=DEV, dtype=BF)
+    part = torch.empty(lib.pk_window_attn_bwd_ws_floats(nw, heads), device=DEV)
+    dtab = torch.empty(169, heads, device=DEV)
+    call("pk_window_attn_bwd", qkv.to(DEV, BF), table.to(DEV), go.to(DEV, BF), lse, dqkv, part, dtab, nw, heads, Cc, stream_ptr())
+    assert err(C(dqkv), qr.grad) < 2e-2
+    assert err(C(dtab), tr.grad) < 2e-2
+
+
+# ------------------------------------------------------------------------------------------------ whole HRFormer block
+@pytest.mark.parametrize("tag", ["a", "b", "d"])
+def test_hrformer_block_vs_golden(golden, N, tag):
+    """Block forward/backward against the reference's fp32 numbers (attn_blocks.npz): bf16 storage between the six fused
+    stages -> 3e-2 norm-wise on outputs and input gradients, 5e-2 on parameter gradients."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    z, meta = golden("attn_blocks.npz"), golden("meta.json")["attn"][f"blk_{tag}"]
+    blk = HRFormerBlock(meta["C"], meta["heads"])
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(meta["spec"], 2).items()})
+    blk = blk.to(DEV)
+    x = torch.from_numpy(z[f"blk_{tag}_x"])
+    xd = nhwc(x).requires_grad_(True)
+    with N.use_weights(blk):
+        y = N.window_block(xd, blk, meta["heads"])
+        assert err(nchw(y), torch.from_numpy(z[f"blk_{tag}_y"])) < 3e-2
+        y.backward(nhwc(torch.from_numpy(z[f"blk_{tag}_gy"])))
+    assert err(nchw(xd.grad), torch.from_numpy(z[f"blk_{tag}_gx"])) < 3e-2
+    for k, p in blk.named_parameters():
+        assert err(C(p.grad), torch.from_numpy(z[f"blk_{tag}_g.{k}"])) < 5e-2, k
+
+
+def test_hrformer_block_droppath_scales(N):
+    """Per-sample DropPath multipliers (0 and 1/keep) against the oracle's block with the same scales."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    from oracle import nets as onet
+    torch.manual_seed(3)
+    blk = HRFormerBlock(32, 1)
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() > 1:
+                p.copy_(q(p * 3))
+    x = rnd(3, 32, 9, 10, seed=4)
+    s1, s2 = torch.tensor([0.0, 1 / 0.9, 1 / 0.9]), torch.tensor([1 / 0.9, 0.0, 1 / 0.9])
+    P = {"b." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in blk.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    y_ref = onet.hrformer_block(xr.permute(0, 2, 3, 1), P, "b", 1, onet.Ctx(drop_scale=lambda key, i: (s1, s2)[i]))
+    gy = rnd(*y_ref.shape, seed=5)
+    y_ref.backward(gy)
+    blk = blk.to(DEV)
+    xd = nhwc(x).requires_grad_(True)
+    with N.use_weights(blk):
+        y = N.window_block(xd, blk, 1, s1.to(DEV), s2.to(DEV))
+        assert err(C(y), y_ref.detach()) < 3e-2
+        y.backward(gy.to(DEV, BF))
+    assert err(nchw(xd.grad), xr.grad) < 3e-2
+    for k, p in blk.named_parameters():
+        assert err(C(p.grad), P["b." + k].grad) < 5e-2, k
+
+
+# ------------------------------------------------------------------------------------------------ exchange unit
+def test_fuse_sum_and_upsample_backward(N):
+    from oracle import nets as onet
+    xs = [rnd(2, 16, 16, 12, seed=1), rnd(2, 16, 8, 6, seed=2), rnd(2, 16, 4, 3, seed=3), rnd(2, 16, 2, 2, seed=4)]
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    ref = torch.relu(xr[0] + sum(onet.upsample_bilinear(t, (16, 12)) for t in xr[1:]))
+    gy = rnd(*ref.shape, seed=5)
+    ref.backward(gy)
+    xd = [nhwc(t).requires_grad_(True) for t in xs]
+    y = N.fuse_sum(xd, True)
+    assert err(nchw(y), ref.detach()) < 8e-3
+    y.backward(nhwc(gy))
+    for a, b in zip(xd, xr):
+        assert err(nchw(a.grad), b.grad) < 1e-2
+    # odd sizes, as F.interpolate(size=...) handles them (9x7 <- 5x4)
+    a, b = rnd(1, 8, 9, 7, seed=6), rnd(1, 8, 5, 4, seed=7)
+    ref2 = a + F.interpolate(b, size=[9, 7], mode="bilinear", align_corners=False)
+    assert err(nchw(N.fuse_sum([nhwc(a), nhwc(b)], False)), ref2) < 8e-3
+
+
+@pytest.mark.parametrize("name,salt", [("fm2", 9), ("basic", 3)])
+def test_modules_vs_golden(golden, name, salt):
+    """A residual block and a whole HRFormer module (2 branches of window blocks + exchange unit), train mode, against
+    the reference's fp32 numbers.  (The golden HRNet modules use 4-channel branches, below the kernels' 8-channel granule.)"""
+    from infantposeestimation_gaussianbias_amd import dispatch
+    from infantposeestimation_gaussianbias_amd.models import hrformer, _blocks
+    z, meta = golden("modules.npz"), golden("meta.json")["modules"]
+    tag = f"{name}_tr"
+    mod = _blocks.Residual(8, 8, False) if name == "basic" else hrformer.HRFormerModule([16, 32], [1, 2], [1, 1], [4, 4], 0.0)
+    mod.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(meta[tag]["spec"], salt).items()})
+    mod = mod.to(DEV).train()
+    assert dispatch.backend_name(mod) == "hip"
+    xs = []
+    while f"{tag}_x{len(xs)}" in z:
+        xs.append(nhwc(torch.from_numpy(z[f"{tag}_x{len(xs)}"])).requires_grad_(True))
+    report = {}
+    with dispatch.scope(mod):
+        ys = mod(list(xs)) if name == "fm2" else [mod(xs[0])]
+        tot = 0
+        for i, y in enumerate(ys):
+            report[f"y{i}"] = err(nchw(y), torch.from_numpy(z[f"{tag}_y{i}"]))
+            tot = tot + (y.float() * nhwc(torch.from_numpy(z[f"{tag}_gy{i}"])).float()).sum()
+        tot.backward()
+    l2 = {}
+    for i, x in enumerate(xs):
+        report[f"gx{i}"] = err(nchw(x.grad), torch.from_numpy(z[f"{tag}_gx{i}"]))
+        l2[f"gx{i}"] = err2(nchw(x.grad), torch.from_numpy(z[f"{tag}_gx{i}"]))
+    for k, p in mod.named_parameters():
+        report["g." + k] = err(C(p.grad), torch.from_numpy(z[f"{tag}_g.{k}"]))
+        l2["g." + k] = err2(C(p.grad), torch.from_numpy(z[f"{tag}_g.{k}"]))
+    print("max-norm", {k: round(v, 4) for k, v in report.items()})
+    print("l2", {k: round(v, 4) for k, v in l2.items()})
+    # outputs: max-norm 3e-2.  gradients: L2 5e-2 (a ReLU mask taken from bf16 values flips a few near-zero elements,
+    # each an O(1) change -> max-norm is only bounded loosely at 0.35)
+    bad = {k: v for k, v in report.items() if v > (3e-2 if k[0] == "y" else 0.35)}
+    bad.update({"l2:" + k: v for k, v in l2.items() if v > 0.1})     # BN over only 24-96 samples in these tiny golden maps
+    assert not bad, bad
+    for k in z:
+        if k.startswith(f"{tag}_buf.") and "running" in k:
+            assert err(C(mod.state_dict()[k[len(tag) + 5:]]), torch.from_numpy(z[k])) < 2e-2, k
+
+
+@pytest.mark.parametrize("Cc,heads,H,W", [(16, 1, 8, 6), (32, 2, 4, 3), (16, 1, 4, 3), (64, 2, 5, 9)])
+def test_hrformer_block_small_channels_vs_oracle(N, Cc, heads, H, W):
+    """Blocks at the channel counts / map sizes of the tiny golden modules (C=16: LayerNorm on 2 lanes, head_dim 16,
+    maps smaller than one window) against the fp32 oracle, recipe weights (O(1) activations)."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    from oracle import nets as onet
+    from recipe import spec_of
+    blk = HRFormerBlock(Cc, heads)
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec_of(blk.state_dict()), 77).items()})
+    with torch.no_grad():
+        for p in blk.parameters():
+            if p.dim() > 1:
+                p.copy_(q(p))
+    x = rnd(2, Cc, H, W, seed=12)
+    P = {"b." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in blk.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    y_ref = onet.hrformer_block(xr.permute(0, 2, 3, 1), P, "b", heads, onet.Ctx())
+    gy = rnd(*y_ref.shape, seed=13)
+    y_ref.backward(gy)
+    blk = blk.to(DEV)
+    xd = nhwc(x).requires_grad_(True)
+    with N.use_weights(blk):
+        y = N.window_block(xd, blk, heads)
+        y.backward(gy.to(DEV, BF))
+    report = {"y": err(C(y), y_ref.detach()), "gx": err(nchw(xd.grad), xr.grad)}
+    for k, p in blk.named_parameters():
+        report["g." + k] = err(C(p.grad), P["b." + k].grad)
+    print("max-norm", {k: round(v, 4) for k, v in report.items()})
+    bad = {k: v for k, v in report.items() if v > 5e-2}
+    assert not bad, bad
+
+
+def test_exchange_unit_vs_oracle(N):
+    """The exchange unit alone (1x1 conv+BN+bilinear up, 3x3 s2 conv(+BN)(+ReLU) chains, sums, ReLU), 3 branches, train mode."""
+    from infantposeestimation_gaussianbias_amd import dispatch
+    from infantposeestimation_gaussianbias_amd.models._blocks import make_fuse_layers
+    from oracle import nets as onet
+    torch.manual_seed(21)
+    fuse = make_fuse_layers([16, 32, 64])
+    with torch.no_grad():
+        for m in fuse.modules():
+            if isinstance(m, torch.nn.Conv2d):
+                m.weight.copy_(q(m.weight * 2))
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+                m.bias.copy_(torch.randn_like(m.bias) * 0.2)
+    xs = [rnd(2, 16, 16, 12, seed=1), rnd(2, 32, 8, 6, seed=2), rnd(2, 64, 4, 3, seed=3)]
+    P = {"f." + k: v.detach().clone().requires_grad_(v.dtype.is_floating_point) for k, v in fuse.state_dict().items()}
+    xr = [t.clone().requires_grad_(True) for t in xs]
+    ys_ref = onet.exchange(xr, P, "f", onet.Ctx(train=True))
+    gys = [rnd(*y.shape, seed=30 + i) for i, y in enumerate(ys_ref)]
+    sum((y * g).sum() for y, g in zip(ys_ref, gys)).backward()
+    holder = Holder(f=fuse).to(DEV).train()
+    xd = [nhwc(t).requires_grad_(True) for t in xs]
+    with dispatch.scope(holder):
+        ys = dispatch.exchange(xd, holder.f, True)
+        sum((y.float() * nhwc(g).float()).sum() for y, g in zip(ys, gys)).backward()
+    report, l2 = {}, {}
+    for i in range(3):
+        report[f"y{i}"] = err(nchw(ys[i]), ys_ref[i].detach())
+        report[f"gx{i}"] = err(nchw(xd[i].grad), xr[i].grad)
+        l2[f"gx{i}"] = err2(nchw(xd[i].grad), xr[i].grad)
+    for k, p in holder.f.named_parameters():
+        report["g." + k] = err(C(p.grad), P["f." + k].grad)
+        l2["g." + k] = err2(C(p.grad), P["f." + k].grad)
+    print("max-norm", {k: round(v, 4) for k, v in report.items()})
+    print("l2", {k: round(v, 4) for k, v in l2.items()})
+    bad = {k: v for k, v in report.items() if v > (2e-2 if k[0] == "y" else 0.35)}
+    bad.update({"l2:" + k: v for k, v in l2.items() if v > 0.1})     # train-mode BN over 24-384 samples: ill-conditioned
+    assert not bad, bad

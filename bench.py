@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of the step instead of launching every kernel eagerly")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -117,8 +118,10 @@ def main():
     cfg = get_config("hrformer_small")
     cfg.train.batch_size = PER_GPU_BATCH
     model = build_model(cfg).to(dev)
-    trainer = engine.Trainer(model, cfg, iters_per_epoch=1000)
+    use_graph = args.graph or os.environ.get("POSE_GRAPH", "0") == "1"
+    trainer = engine.Trainer(model, cfg, iters_per_epoch=1000, use_graph=use_graph, graph_warmup=2)
     batch = synthetic_batch(PER_GPU_BATCH, INPUT_SIZE, HEATMAP_SIZE, K, 2.0, dev, seed=1234 + rank)
+    args.warmup = max(args.warmup, 4) if use_graph else args.warmup      # 2 eager steps + capture + 1 replay before timing
 
     out = None
     for i in range(args.warmup):
@@ -160,7 +163,8 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "HRFormer-small + fusion head, 256x192 -> 64x48, K=17, train step fwd+bwd+AdamW, DropPath 0.1, BN train",
-                       "global_batch": PER_GPU_BATCH * world, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}"},
+                       "global_batch": PER_GPU_BATCH * world, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}",
+                       "launch": "hipGraph replay" if trainer._graph is not None else "eager"},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
             "impl": dict(impl_table, loss="hip", target="hip", decode="hip", adamw="hip"),
             "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP; 'aten' entries are PyTorch-ROCm stop-gaps",

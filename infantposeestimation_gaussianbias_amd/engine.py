@@ -266,9 +266,15 @@ class GradientExchange:
 
 
 class Trainer:
-    """One optimisation step of train.py::train_one_epoch (:169-187) without its per-step host syncs."""
+    """One optimisation step of train.py::train_one_epoch (:169-187) without its per-step host syncs.
 
-    def __init__(self, model, cfg, iters_per_epoch: int, bucket_mb: float = 16.0):
+    `use_graph=True` captures zero_grad + forward + backward (+ the optimiser when single-GPU) of a fixed-shape batch into
+    a hipGraph after `graph_warmup` eager steps and replays it: ~3 300 kernel launches per step become one graph launch,
+    which removes the host as the bottleneck.  With N>1 ranks the gradient all-reduce and the optimiser run eagerly
+    between replays (RCCL is kept out of the capture).  The LR is written to a device scalar before each replay, so the
+    per-iteration schedule advances normally.  Batches are copied into static input buffers."""
+
+    def __init__(self, model, cfg, iters_per_epoch: int, bucket_mb: float = 16.0, use_graph: bool = False, graph_warmup: int = 3):
         self.model, self.cfg = model, cfg
         t = cfg.train
         if t.optimizer != "AdamW":
@@ -277,14 +283,75 @@ class Trainer:
         self.sched = WarmupMultiStepLR(self.opt, t, iters_per_epoch)
         self.comm = GradientExchange(self.opt, bucket_mb)
         self.comm.broadcast_initial_state()
+        self.use_graph, self.graph_warmup = use_graph, graph_warmup
+        # autograd binds each AccumulateGrad node to the stream that was current when it was created; warm-up and
+        # capture therefore run on ONE dedicated side stream, otherwise backward would sync with the (non-capturing)
+        # default stream in the middle of the capture
+        self._stream = torch.cuda.Stream() if (use_graph and torch.cuda.is_available()) else None
+        self._eager_steps = 0
+        self._graph = None
+        self._static = None
+        self._static_out = None
 
-    def step(self, batch):
-        self.model.train()
+    # -- eager path --------------------------------------------------------------------------------------------
+    def _fwd_bwd(self, batch):
         self.opt.zero_grad()
         out = self.model(batch["img"], batch["target"], batch["target_weight"], gt_keypoints=batch.get("keypoints"),
                          input_size=self.cfg.data.input_size)
         out["loss"].backward()
+        return out
+
+    def _eager_step(self, batch):
+        self.model.train()
+        out = self._fwd_bwd(batch)
         self.comm.finish()
         self.opt.step(self.comm.grad_scale)
         self.sched.step()
         return out
+
+    # -- graph path --------------------------------------------------------------------------------------------
+    def _capture(self, batch):
+        keys = [k for k in ("img", "target", "target_weight", "keypoints") if batch.get(k) is not None]
+        self._static = {k: batch[k].clone() for k in keys}
+        self._graph_has_opt = self.comm.world == 1
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=self._stream):
+            out = self._fwd_bwd(self._static)
+            if self._graph_has_opt:
+                self.opt.step(1.0)
+        self._graph, self._static_out = g, out
+
+    def _graph_step(self, batch):
+        for k, v in self._static.items():
+            v.copy_(batch[k], non_blocking=True)
+        self._graph.replay()
+        if self._graph_has_opt:
+            self.opt.step_count += 1          # the captured pk_adamw_step already advanced the device-side counter
+        else:
+            self.comm.finish()
+            self.opt.step(self.comm.grad_scale)
+        self.sched.step()
+        return self._static_out
+
+    def step(self, batch):
+        if not self.use_graph:
+            return self._eager_step(batch)
+        if self._graph is None:
+            if self._eager_steps < self.graph_warmup:
+                self._eager_steps += 1
+                self._stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self._stream):
+                    out = self._eager_step(batch)
+                torch.cuda.current_stream().wait_stream(self._stream)
+                return out
+            self.model.train()
+            if self.comm.world > 1 and self.comm._armed:
+                for h in self.comm._hooks:        # hooks would fire inside the capture: reduce after the replay instead
+                    h.remove()
+                self.comm._hooks.clear()
+                for bk in self.comm.buckets:
+                    bk["need"] = -2               # never "complete" by counting; finish() flushes every bucket
+            self._capture(batch)
+            # the capture itself does not execute: run this step through the graph
+        return self._graph_step(batch)

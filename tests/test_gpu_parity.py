@@ -328,3 +328,23 @@ def test_trainer_two_steps_loss_decreases_and_is_deterministic():
     assert losses[0][-1] < losses[0][0]
     assert math.isclose(losses[0][0], losses[1][0], rel_tol=2e-3)       # same weights, same batch: same first loss
     assert np.allclose(losses[0], losses[1], rtol=5e-2)                 # later steps: Adam amplifies reduction-order noise
+
+
+def test_graph_replay_matches_eager_steps():
+    """The captured hipGraph step (zero_grad + fwd + bwd + AdamW) follows the same loss trajectory as eager launches."""
+    from infantposeestimation_gaussianbias_amd import engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    batches = [synthetic_batch(4, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=30 + i) for i in range(3)]
+    traj = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        model = build_model(cfg).to(DEV)
+        model.backbone.drop_path_rate = 0.0
+        tr = engine.Trainer(model, cfg, iters_per_epoch=2, use_graph=mode, graph_warmup=2)
+        traj[mode] = [float(tr.step(batches[i % 3])["loss"].detach()) for i in range(7)]
+        assert (tr._graph is not None) == mode
+    assert np.allclose(traj[False], traj[True], rtol=2e-3), traj

@@ -276,7 +276,10 @@ __global__ void __launch_bounds__(256) k_relbias_scatter(const float* __restrict
 }
 
 extern "C" int pk_window_attn_bwd_groups(int n_windows, int heads) {
-    int per_head = n_windows < 256 ? n_windows : 256;
+    // one 64-lane workgroup per (window-group, head); aim for >= 1024 workgroups so every CU holds several waves
+    int per_head = (1024 + heads - 1) / heads;
+    if (per_head < 64) per_head = 64;
+    if (per_head > n_windows) per_head = n_windows;
     return per_head * heads;
 }
 extern "C" int pk_window_attn_bwd_ws_floats(int n_windows, int heads) {

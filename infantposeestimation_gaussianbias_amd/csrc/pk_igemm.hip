@@ -53,56 +53,83 @@ __device__ __forceinline__ float gelu_grad(float z) {
     return 0.5f * (1.f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
 }
 
-template <int BN, int WM, int WN>  // WM x WN waves; wave tile = (BM/WM) x (BN/WN)
-__global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
+// ================================================================================================ main kernel (v2)
+// Same contraction and epilogue as above, restructured so the K loop is MFMA-bound instead of issue-bound:
+//   * filter taps are the OUTER loop: per tap each thread computes ONE byte offset per staged row (bounds, dilation);
+//     the inner loop over channel chunks only bumps a scalar offset;
+//   * every global read is a branch-free `buffer_load_dwordx4`: an out-of-image tap, a row beyond M, a pad token or a
+//     channel beyond Cin gets the offset 0x80000000 >= num_records and the hardware returns zeros;
+//   * LDS tiles are unpadded and XOR-swizzled per 16-byte chunk (conflict-free ds_read_b128 for both K-steps:
+//     BK=64: chunk ^= (row>>1)&7, BK=32: chunk ^= (row>>3)<<1, found by exhaustive search over the b128 lane groups).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+#define OOB_OFF 0x80000000u
+
+template <int BK>
+__device__ __forceinline__ int swz(int row) { return BK == 64 ? ((row >> 1) & 7) : (((row >> 3) & 1) << 1); }
+
+template <int BN, int WM, int WN, int BK>
+__global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
-    constexpr int B_CHUNKS = BN * 4;  // 16-byte chunks of the weight tile
-    __shared__ __attribute__((aligned(16))) uint16_t sA[2][BM * LDS_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t sB[2][BN * LDS_PITCH];
-    __shared__ float sStat[WM][BN][2];
+    constexpr int CH = BK / 8;                       // 16-byte chunks per tile row
+    constexpr int A_PT = BM * CH / 256;              // A chunks per thread (2 or 4)
+    constexpr int B_PT = (BN * CH + 255) / 256;      // B chunks per thread (1..4)
+    constexpr int KS = BK / 32;                      // MFMA k-steps per staged tile
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BM * BK + 2 * BN * BK];
+    uint16_t* sA = smem;                             // [2][BM*BK]
+    uint16_t* sB = smem + 2 * BM * BK;               // [2][BN*BK]
+    float* sStat = reinterpret_cast<float*>(smem);   // [WM][BN][2], reused after the main loop
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    // ---- per-thread staging descriptors: two A chunks (rows r, r+64; 8 channels at kc*8) and up to two B chunks
-    const int kc = tid & 3;
-    int a_off[2];     // element offset of the row's tap (0,0), channel 0 (conv) or of the row start (linear)
-    int a_iy[2], a_ix[2];
-    bool a_ok[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = m0 + (tid >> 2) + 64 * i;
-        a_ok[i] = m < p.M;
-        a_off[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
-        if (!a_ok[i]) continue;
-        if (p.T == 1 && p.Ho == 0) {  // linear
-            int src = p.a_rowmap ? p.a_rowmap[m] : m;
-            a_ok[i] = src >= 0;
-            a_off[i] = src * p.Cin;
-        } else {
-            const int hw = p.Ho * p.Wo, b = m / hw, r = m - b * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
-            a_iy[i] = oy * p.stride - p.pad;
-            a_ix[i] = ox * p.stride - p.pad;
-            a_off[i] = b * p.Hs * p.Ws * p.Cin;
-        }
-    }
     const bool linear = (p.T == 1 && p.Ho == 0);
     const int kw_n = (p.T == 9) ? 3 : 1;
-    const int kchunks = (p.Cin + BKK - 1) / BKK;   // K-steps per tap
+    const int kc = tid % CH;                         // this thread's chunk column (same for all its rows: 256 % CH == 0)
+    const int row0 = tid / CH;                       // first staged row; further rows are +256/CH apart
+    constexpr int RSTEP = 256 / CH;
+
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, 0x7ffffff0, 0x00020000);
+
+    // ---- fixed per-thread row descriptors
+    int a_base[A_PT], a_iy[A_PT], a_ix[A_PT];
+    bool a_ok[A_PT];
+#pragma unroll
+    for (int i = 0; i < A_PT; ++i) {
+        const int m = m0 + row0 + RSTEP * i;
+        a_ok[i] = m < p.M;
+        a_base[i] = 0; a_iy[i] = 0; a_ix[i] = 0;
+        if (a_ok[i]) {
+            if (linear) {
+                const int src = p.a_rowmap ? p.a_rowmap[m] : m;
+                a_ok[i] = src >= 0;
+                a_base[i] = src * p.Cin;
+            } else {
+                const int hw = p.Ho * p.Wo, b = m / hw, r = m - b * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
+                a_iy[i] = oy * p.stride - p.pad;
+                a_ix[i] = ox * p.stride - p.pad;
+                a_base[i] = b * p.Hs * p.Ws * p.Cin;
+            }
+        }
+    }
+    unsigned b_off[B_PT];
+#pragma unroll
+    for (int i = 0; i < B_PT; ++i) {
+        const int q = tid + 256 * i, n = n0 + q / CH;
+        b_off[i] = (q < BN * CH && n < p.N) ? (unsigned)((n * p.T * p.Cin + kc * 8) * 2) : OOB_OFF;
+    }
+    const int kchunks = (p.Cin + BK - 1) / BK;
     const int nk = p.T * kchunks;
 
-    uint4 ra[2], rb[2];
-    auto load_tiles = [&](int kt) {
-        const int t = kt / kchunks, c0 = (kt - t * kchunks) * BKK + kc * 8;
+    unsigned a_voff[A_PT];           // byte offset of (row, current tap, channel kc*8), or OOB
+    auto set_tap = [&](int t) {
         const int kh = t / kw_n, kw = t - kh * kw_n;
-        const bool c_ok = c0 < p.Cin;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (a_ok[i] && c_ok) {
+        for (int i = 0; i < A_PT; ++i) {
+            unsigned off = OOB_OFF;
+            if (a_ok[i]) {
                 if (linear) {
-                    v = *reinterpret_cast<const uint4*>(p.x + a_off[i] + c0);
+                    off = (unsigned)((a_base[i] + kc * 8) * 2);
                 } else {
                     int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
                     bool ok = true;
@@ -112,30 +139,32 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
                         ix >>= 1;
                     }
                     if (ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
-                        v = *reinterpret_cast<const uint4*>(p.x + a_off[i] + (iy * p.Ws + ix) * p.Cin + c0);
+                        off = (unsigned)((a_base[i] + (iy * p.Ws + ix) * p.Cin + kc * 8) * 2);
                 }
             }
-            ra[i] = v;
+            a_voff[i] = off;
         }
+    };
+    u32x4 ra[A_PT], rb[B_PT];
+    auto load_tiles = [&](int t, int c0) {       // c0: first channel of this K-chunk (wave-uniform)
+        const bool c_ok = (c0 + kc * 8) < p.Cin;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = tid + 256 * i;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (ch < B_CHUNKS) {
-                const int n = n0 + (ch >> 2);
-                if (n < p.N && c_ok) v = *reinterpret_cast<const uint4*>(p.w + ((size_t)n * p.T + t) * p.Cin + c0);
-            }
-            rb[i] = v;
-        }
+        for (int i = 0; i < A_PT; ++i)
+            ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, c_ok ? a_voff[i] : OOB_OFF, c0 * 2, 0);
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i)
+            rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, c_ok ? b_off[i] : OOB_OFF, (t * p.Cin + c0) * 2, 0);
     };
     auto store_tiles = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<uint4*>(&sA[buf][((tid >> 2) + 64 * i) * LDS_PITCH + kc * 8]) = ra[i];
+        for (int i = 0; i < A_PT; ++i) {
+            const int row = row0 + RSTEP * i;
+            *reinterpret_cast<u32x4*>(&sA[buf * BM * BK + row * BK + ((kc ^ swz<BK>(row)) * 8)]) = ra[i];
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int ch = tid + 256 * i;
-            if (ch < B_CHUNKS) *reinterpret_cast<uint4*>(&sB[buf][(ch >> 2) * LDS_PITCH + kc * 8]) = rb[i];
+        for (int i = 0; i < B_PT; ++i) {
+            const int q = tid + 256 * i, row = q / CH;
+            if (q < BN * CH) *reinterpret_cast<u32x4*>(&sB[buf * BN * BK + row * BK + ((kc ^ swz<BK>(row)) * 8)]) = rb[i];
         }
     };
 
@@ -145,25 +174,43 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    load_tiles(0);
+    int t_next = 0, c_next = 0;           // (tap, chunk) of the tile being loaded
+    set_tap(0);
+    load_tiles(0, 0);
     store_tiles(0);
     __syncthreads();
-    const int frow = lane & 15, fk = (lane >> 4) * 8;
+    const int frow = lane & 15, fkc = lane >> 4;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_tiles(kt + 1);
-        bf16x8 wf[NI], af[MI];
+        const bool more = kt + 1 < nk;
+        if (more) {
+            c_next += BK;
+            if (c_next >= p.Cin) {
+                c_next = 0;
+                ++t_next;
+                set_tap(t_next);
+            }
+            load_tiles(t_next, c_next);
+        }
 #pragma unroll
-        for (int a = 0; a < NI; ++a)
-            wf[a] = *reinterpret_cast<const bf16x8*>(&sB[buf][(wn * (BN / WN) + a * 16 + frow) * LDS_PITCH + fk]);
+        for (int ks = 0; ks < KS; ++ks) {
+            bf16x8 wf[NI], af[MI];
 #pragma unroll
-        for (int b = 0; b < MI; ++b)
-            af[b] = *reinterpret_cast<const bf16x8*>(&sA[buf][(wm * (BM / WM) + b * 16 + frow) * LDS_PITCH + fk]);
+            for (int a = 0; a < NI; ++a) {
+                const int row = wn * (BN / WN) + a * 16 + frow;
+                wf[a] = *reinterpret_cast<const bf16x8*>(&sB[buf * BN * BK + row * BK + (((fkc + 4 * ks) ^ swz<BK>(row)) * 8)]);
+            }
 #pragma unroll
-        for (int a = 0; a < NI; ++a)
+            for (int b = 0; b < MI; ++b) {
+                const int row = wm * (BM / WM) + b * 16 + frow;
+                af[b] = *reinterpret_cast<const bf16x8*>(&sA[buf * BM * BK + row * BK + (((fkc + 4 * ks) ^ swz<BK>(row)) * 8)]);
+            }
 #pragma unroll
-            for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], af[b], acc[a][b], 0, 0, 0);
-        if (kt + 1 < nk) store_tiles(buf ^ 1);
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], af[b], acc[a][b], 0, 0, 0);
+        }
+        if (more) store_tiles(buf ^ 1);
         __syncthreads();
     }
 
@@ -187,8 +234,8 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
                 }
                 if ((lane & 15) == 0) {
                     const int nl = wn * (BN / WN) + a * 16 + (lane >> 4) * 4 + r;
-                    sStat[wm][nl][0] = s;
-                    sStat[wm][nl][1] = q;
+                    sStat[(wm * BN + nl) * 2] = s;
+                    sStat[(wm * BN + nl) * 2 + 1] = q;
                 }
             }
         }
@@ -197,8 +244,8 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) {
-                s += sStat[w][tid][0];
-                q += sStat[w][tid][1];
+                s += sStat[(w * BN + tid) * 2];
+                q += sStat[(w * BN + tid) * 2 + 1];
             }
             float* dst = p.stats + (size_t)blockIdx.x * 2 * p.N;
             dst[n0 + tid] = s;
@@ -223,13 +270,37 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
         for (int a = 0; a < NI; ++a) {
             const int n = n0 + wn * (BN / WN) + a * 16 + (lane >> 4) * 4;
             if (n >= p.N) continue;
+            const bool full = n + 3 < p.N;
+            const size_t base = (size_t)orow * p.ldo + n;
             float v[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float t = acc[a][b][r];
                 if (p.bias && n + r < p.N) t += p.bias[n + r];
-                if (p.preact && n + r < p.N) p.preact[(size_t)orow * p.ldo + n + r] = f32_to_bf16(t);
-                if (p.gelu_of && n + r < p.N) t *= gelu_grad(bf16_to_f32(p.gelu_of[(size_t)orow * p.ldo + n + r]));
+                v[r] = t;
+            }
+            if (p.preact) {
+                if (full) {
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(p.preact + base) = pk;
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) p.preact[base + r] = f32_to_bf16(v[r]);
+                }
+            }
+            if (p.gelu_of) {
+                if (full) {
+                    const uint2 zz = *reinterpret_cast<const uint2*>(p.gelu_of + base);
+                    v[0] *= gelu_grad(bf16_to_f32((uint16_t)(zz.x & 0xffff))); v[1] *= gelu_grad(bf16_to_f32((uint16_t)(zz.x >> 16)));
+                    v[2] *= gelu_grad(bf16_to_f32((uint16_t)(zz.y & 0xffff))); v[3] *= gelu_grad(bf16_to_f32((uint16_t)(zz.y >> 16)));
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] *= gelu_grad(bf16_to_f32(p.gelu_of[base + r]));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float t = v[r];
                 if (p.act == 1) t = gelu_erf(t);
                 else if (p.act == 2) t = softplus_(t);
                 v[r] = t * rs;
@@ -242,9 +313,8 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
                     if (n + r < p.N) o[(size_t)r * hw_out] = v[r];
                 continue;
             }
-            const size_t base = (size_t)orow * p.ldo + n;
             if (p.res) {
-                if (n + 3 < p.N) {
+                if (full) {
                     const uint2 rv = *reinterpret_cast<const uint2*>(p.res + base);
                     v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
                     v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
@@ -254,7 +324,7 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
             }
             if (p.out_mode == 0) {
                 uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + base;
-                if (n + 3 < p.N) {
+                if (full) {
                     uint2 pk;
                     pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
                     pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
@@ -264,7 +334,7 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
                 }
             } else {
                 float* o = reinterpret_cast<float*>(p.out) + base;
-                if (n + 3 < p.N) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                if (full) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
                 else
                     for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = v[r];
             }
@@ -275,12 +345,16 @@ __global__ void __launch_bounds__(256) k_igemm(IgemmArgs p) {
 static int igemm_launch(const IgemmArgs& a, hipStream_t st, const char* who) {
     const dim3 block(256);
     const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
+    const bool k64 = (a.Cin % 64) == 0;              // deeper K-chunks when the channel count allows full 64-wide tiles
     if (a.N > 64) {
-        hipLaunchKernelGGL((k_igemm<128, 2, 2>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<128, 2, 2, 64>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<128, 2, 2, 32>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
     } else if (a.N > 32) {
-        hipLaunchKernelGGL((k_igemm<64, 4, 1>), dim3(gm, 1), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<64, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<64, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
     } else {
-        hipLaunchKernelGGL((k_igemm<32, 4, 1>), dim3(gm, 1), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<32, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<32, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
     }
     return pk_launch_status(who);
 }
@@ -295,7 +369,7 @@ static int check_common(const char* who, const void* x, const void* w, const voi
         PK_REQUIRE(ldo >= N, "%s: ldo=%d < N=%d", who, ldo, N);
         PK_REQUIRE((ldo & 3) == 0 && ((uintptr_t)out & 15) == 0, "%s: output pitch must be a multiple of 4 and 16-byte aligned", who);
     }
-    PK_REQUIRE((int64_t)M * (ldo > Cin ? ldo : Cin) < 0x7fffffffLL, "%s: tensor too large for 32-bit offsets", who);
+    PK_REQUIRE((int64_t)M * (ldo > Cin ? ldo : Cin) < 0x3fffffffLL, "%s: tensor too large for 32-bit byte offsets", who);
     return PK_OK;
 }
 
@@ -316,7 +390,8 @@ extern "C" int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, fl
                    "pk_conv2d_nhwc: output %dx%d does not match input %dx%d k=%d s=%d", Ho, Wo, Hs, Ws, ksize, stride);
     }
     PK_REQUIRE(out_mode >= 0 && out_mode <= 2 && act >= 0 && act <= 2, "pk_conv2d_nhwc: bad mode");
-    PK_REQUIRE((int64_t)B * Hs * Ws * Cin < 0x7fffffffLL, "pk_conv2d_nhwc: input too large for 32-bit offsets");
+    PK_REQUIRE((int64_t)B * Hs * Ws * Cin < 0x3fffffffLL && (int64_t)Cout * ksize * ksize * Cin < 0x3fffffffLL,
+               "pk_conv2d_nhwc: input too large for 32-bit byte offsets");
     PK_REQUIRE(out_mode == 2 || (Cout & 3) == 0, "pk_conv2d_nhwc: Cout=%d must be a multiple of 4 for row-major output", Cout);
     IgemmArgs a{};
     a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_packed; a.out = out; a.bias = bias; a.stats = stats_partial;
@@ -478,13 +553,13 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 }
 
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
-    // enough workgroups to fill 256 CUs several times over, but no slice shorter than 512 rows
+    // enough workgroups to fill 256 CUs several times over (>= 2048), but no slice shorter than 256 rows
     const int tiles = ((N + 63) / 64) * ((Cin + 63) / 64) * T;
     int s = (2048 + tiles - 1) / tiles;
-    const int max_s = (M + 511) / 512;
+    const int max_s = (M + 255) / 256;
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
-    if (s > 64) s = 64;
+    if (s > 512) s = 512;
     return s;
 }
 

@@ -48,29 +48,22 @@ def time_kernel(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def roofline_of_dominant_kernel(batch, out):
-    """Dominant *hand-written* kernel of the step today: k_floss_bwd (pk_fusion_loss_bwd), HBM-bound.
-    Algorithmic bytes per launch = read heatmaps + target, write d_heatmaps + d_variances + d_offsets(2 planes)
-    = 6 maps x B*K*H*W*4 B."""
-    from infantposeestimation_gaussianbias_amd import hipops
-    from infantposeestimation_gaussianbias_amd._lib import call, stream_ptr
-    hm, off, var = (out[k].detach().float().contiguous() for k in ("heatmaps", "offsets", "variances"))
-    B, Kk, H, W = hm.shape
-    lam = torch.tensor([1.0, 1.0, 0.5, 0.1, 0.05, 0.05], device=hm.device)
-    ws = torch.empty(hipops.loss_ws_floats(B, Kk), device=hm.device)
-    losses = torch.empty(7, device=hm.device)
-    tgt, w, gt = batch["target"], batch["target_weight"], batch["keypoints"]
-    call("pk_fusion_loss_fwd", hm, off, var, tgt, w, gt, ws, losses, B, Kk, H, W, float(INPUT_SIZE[0]), float(INPUT_SIZE[1]), 2.0, lam, stream_ptr())
-    dhm, doff, dvar = torch.empty_like(hm), torch.empty_like(off), torch.empty_like(var)
-
-    def launch():
-        call("pk_fusion_loss_bwd", hm, off, var, tgt, w, ws, None, dhm, doff, dvar, B, Kk, H, W, 2.0, lam, stream_ptr())
-    sec = time_kernel(launch)
-    alg_bytes = 6 * B * Kk * H * W * 4
-    achieved = alg_bytes / sec / 1e9
-    return {"kernel": "k_floss_bwd", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "us_per_launch": round(sec * 1e6, 2),
-            "algorithmic_bytes": alg_bytes}
+def roofline_of_dominant_kernel(model):
+    """Dominant kernel of the step (rocprof, profiles/): k_igemm2<128,2,2,64> on the fusion head's 3x3 256->256 convs at
+    64x48 (fusion_head.py:215,224,235): 12 launches per step (forward + data-gradient), MFMA-bound.
+    Algorithmic flops per launch = 2*M*N*K = 2 * (B*64*48) * 256 * (9*256) = 232 GFLOP at B=64 (3.62 GFLOP/img)."""
+    from infantposeestimation_gaussianbias_amd import nnops
+    conv = model.head.shared_layers["3"]
+    B, H, W, C = PER_GPU_BATCH, HEATMAP_SIZE[1], HEATMAP_SIZE[0], conv.weight.shape[1]
+    x = torch.randn(B, H, W, C, device=conv.weight.device).to(torch.bfloat16)
+    with nnops.use_weights(model) as wc:
+        wf = wc.fwd[id(conv.weight)]
+        sec = time_kernel(lambda: nnops._conv_raw(x, wf, conv.weight.shape[0], 3, 1, True))
+    flops = 2.0 * B * H * W * conv.weight.shape[0] * 9 * C
+    achieved = flops / sec / 1e12
+    return {"kernel": "k_igemm2<128,2,2,64> (head conv3x3 256->256 @64x48, fwd + BN-stat epilogue)", "bound": "mfma",
+            "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
+            "traffic": None, "us_per_launch": round(sec * 1e6, 1), "algorithmic_flops": flops}
 
 
 def cpu_baseline():
@@ -93,7 +86,7 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true", help="replay a captured hipGraph of the step instead of launching every kernel eagerly")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph of the step")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -118,7 +111,7 @@ def main():
     cfg = get_config("hrformer_small")
     cfg.train.batch_size = PER_GPU_BATCH
     model = build_model(cfg).to(dev)
-    use_graph = args.graph or os.environ.get("POSE_GRAPH", "0") == "1"
+    use_graph = not args.no_graph and os.environ.get("POSE_NO_GRAPH", "0") != "1"
     trainer = engine.Trainer(model, cfg, iters_per_epoch=1000, use_graph=use_graph, graph_warmup=2)
     batch = synthetic_batch(PER_GPU_BATCH, INPUT_SIZE, HEATMAP_SIZE, K, 2.0, dev, seed=1234 + rank)
     args.warmup = max(args.warmup, 4) if use_graph else args.warmup      # 2 eager steps + capture + 1 replay before timing
@@ -149,7 +142,7 @@ def main():
 
     if rank == 0:
         log(f"timed region: {dt:.3f} s for {args.steps} steps -> {PER_GPU_BATCH * world * args.steps / dt:.1f} img/s")
-        roof = roofline_of_dominant_kernel(batch, out)
+        roof = roofline_of_dominant_kernel(model)
         log(f"roofline kernel timed: {roof}")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:

@@ -250,10 +250,19 @@ __global__ void __launch_bounds__(64) k_win_attn_bwd(const uint16_t* __restrict_
 //   A) tmp[h][i*49+j] = sum over the workgroups of head h of their register-accumulated dS (coalesced over ij)
 //   B) dtable[e][h]   = sum over the <= 49 (i,j) pairs with rel_index(i,j) == e
 __global__ void __launch_bounds__(256) k_relbias_reduce(const float* __restrict__ part, int n_groups, int heads, float* __restrict__ tmp) {
-    const int ij = blockIdx.x * blockDim.x + threadIdx.x, h = blockIdx.y;
-    if (ij >= AT_N * AT_N) return;
+    // block = 16 (i,j) entries x 16 group-lanes; fixed-order combine (deterministic), chain length n_groups/(16*heads)
+    __shared__ float sh[16][17];
+    const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int ij = blockIdx.x * 16 + col, h = blockIdx.y;
     float s = 0.f;
-    for (int g = h; g < n_groups; g += heads) s += part[(size_t)g * AT_N * AT_N + ij];
+    if (ij < AT_N * AT_N)
+        for (int g = h + rl * heads; g < n_groups; g += 16 * heads) s += part[(size_t)g * AT_N * AT_N + ij];
+    sh[rl][col] = s;
+    __syncthreads();
+    if (rl != 0 || ij >= AT_N * AT_N) return;
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += sh[r][col];
     tmp[(size_t)h * AT_N * AT_N + ij] = s;
 }
 __global__ void __launch_bounds__(256) k_relbias_scatter(const float* __restrict__ tmp, int heads, float* __restrict__ dtable) {
@@ -297,7 +306,7 @@ extern "C" int pk_window_attn_bwd(const void* qkv, const float* rel_table, const
                        (uint16_t*)dqkv, dbias_partial, n_windows, heads, C, d, 1.f / sqrtf((float)d), groups / heads);
     // stage-A output reuses the tail of the partial buffer (caller sizes it for groups + heads tiles)
     float* tmp = dbias_partial + (size_t)groups * AT_N * AT_N;
-    hipLaunchKernelGGL(k_relbias_reduce, dim3((AT_N * AT_N + 255) / 256, heads), dim3(256), 0, st, dbias_partial, groups, heads, tmp);
+    hipLaunchKernelGGL(k_relbias_reduce, dim3((AT_N * AT_N + 15) / 16, heads), dim3(256), 0, st, dbias_partial, groups, heads, tmp);
     hipLaunchKernelGGL(k_relbias_scatter, dim3((169 * heads + 255) / 256), dim3(256), 0, st, tmp, heads, dtable);
     return pk_launch_status("pk_window_attn_bwd");
 }

@@ -537,18 +537,28 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs p) {
         }
 }
 
-// out[...] = sum_s part[s][n][t][c]; layout 0: [N][T][Cin]; layout 1: OIHW = [N][Cin][T] (reference conv weight layout)
+// out[...] = sum_s part[s][n][t][c]; layout 0: [N][T][Cin]; layout 1: OIHW = [N][Cin][T] (reference conv weight layout).
+// Block = 16 elements x 16 slice-lanes (lane r sums slices s = r mod 16, fixed-order combine): short dependency chains
+// even with hundreds of slices, still deterministic.
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ out, int S, int N, int T,
                                                       int Cin, int layout) {
+    __shared__ float sh[16][17];
     const int total = N * T * Cin;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        for (int k = 0; k < S; ++k) s += part[(size_t)k * total + i];
-        if (layout == 0) out[i] = s;
-        else {
-            const int c = i % Cin, t = (i / Cin) % T, n = i / (Cin * T);
-            out[((size_t)n * Cin + c) * T + t] = s;
-        }
+    const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + col;
+    float s = 0.f;
+    if (i < total)
+        for (int k = rl; k < S; k += 16) s += part[(size_t)k * total + i];
+    sh[rl][col] = s;
+    __syncthreads();
+    if (rl != 0 || i >= total) return;
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += sh[r][col];
+    if (layout == 0) out[i] = s;
+    else {
+        const int c = i % Cin, t = (i / Cin) % T, n = i / (Cin * T);
+        out[((size_t)n * Cin + c) * T + t] = s;
     }
 }
 
@@ -583,8 +593,6 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_wgrad, dim3(((N + 63) / 64) * a.ctiles, a.T, S), dim3(256), 0, st, a);
     const int total = N * a.T * Cin;
-    int nb = (total + 255) / 256;
-    if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3(nb), dim3(256), 0, st, workspace, dw, S, N, a.T, Cin, out_layout);
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 15) / 16), dim3(256), 0, st, workspace, dw, S, N, a.T, Cin, out_layout);
     return pk_launch_status("pk_wgrad_bf16");
 }

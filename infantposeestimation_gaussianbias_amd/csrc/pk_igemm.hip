@@ -67,6 +67,89 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 template <int BK>
 __device__ __forceinline__ int swz(int row) { return BK == 64 ? ((row >> 1) & 7) : (((row >> 3) & 1) << 1); }
 
+// Epilogue of ONE 16x16 accumulator tile: this lane owns output row `orow` (pixel / token) and columns n..n+3.
+// Kept as a force-inlined function with only static register indexing so the accumulator array stays in registers
+// (an epilogue written inline with `continue`s and tail loops made hipcc index acc[][] dynamically -> scratch).
+__device__ __forceinline__ void igemm_epilogue_tile(const IgemmArgs& p, f32x4 c, int orow, int n, float rs, int hw_out) {
+    if (n >= p.N) return;
+    const bool full = n + 3 < p.N;
+    const size_t base = (size_t)orow * p.ldo + n;
+    float v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
+    if (p.bias) {
+        v0 += p.bias[n];
+        if (n + 1 < p.N) v1 += p.bias[n + 1];
+        if (n + 2 < p.N) v2 += p.bias[n + 2];
+        if (n + 3 < p.N) v3 += p.bias[n + 3];
+    }
+    if (p.preact) {
+        if (full) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+            *reinterpret_cast<uint2*>(p.preact + base) = pk;
+        } else {
+            p.preact[base] = f32_to_bf16(v0);
+            if (n + 1 < p.N) p.preact[base + 1] = f32_to_bf16(v1);
+            if (n + 2 < p.N) p.preact[base + 2] = f32_to_bf16(v2);
+        }
+    }
+    if (p.gelu_of) {
+        if (full) {
+            const uint2 zz = *reinterpret_cast<const uint2*>(p.gelu_of + base);
+            v0 *= gelu_grad(bf16_to_f32((uint16_t)(zz.x & 0xffff))); v1 *= gelu_grad(bf16_to_f32((uint16_t)(zz.x >> 16)));
+            v2 *= gelu_grad(bf16_to_f32((uint16_t)(zz.y & 0xffff))); v3 *= gelu_grad(bf16_to_f32((uint16_t)(zz.y >> 16)));
+        } else {
+            v0 *= gelu_grad(bf16_to_f32(p.gelu_of[base]));
+            if (n + 1 < p.N) v1 *= gelu_grad(bf16_to_f32(p.gelu_of[base + 1]));
+            if (n + 2 < p.N) v2 *= gelu_grad(bf16_to_f32(p.gelu_of[base + 2]));
+        }
+    }
+    if (p.act == 1) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
+    else if (p.act == 2) { v0 = softplus_(v0); v1 = softplus_(v1); v2 = softplus_(v2); v3 = softplus_(v3); }
+    v0 *= rs; v1 *= rs; v2 *= rs; v3 *= rs;
+    if (p.out_mode == 2) {
+        const int bb = orow / hw_out, pix = orow - bb * hw_out;
+        float* o = reinterpret_cast<float*>(p.out) + ((size_t)bb * p.N + n) * hw_out + pix;
+        o[0] = v0;
+        if (n + 1 < p.N) o[(size_t)hw_out] = v1;
+        if (n + 2 < p.N) o[(size_t)2 * hw_out] = v2;
+        if (n + 3 < p.N) o[(size_t)3 * hw_out] = v3;
+        return;
+    }
+    if (p.res) {
+        if (full) {
+            const uint2 rv = *reinterpret_cast<const uint2*>(p.res + base);
+            v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
+            v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+        } else {
+            v0 += bf16_to_f32(p.res[base]);
+            if (n + 1 < p.N) v1 += bf16_to_f32(p.res[base + 1]);
+            if (n + 2 < p.N) v2 += bf16_to_f32(p.res[base + 2]);
+        }
+    }
+    if (p.out_mode == 0) {
+        uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + base;
+        if (full) {
+            uint2 pk;
+            pk.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
+            pk.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
+            *reinterpret_cast<uint2*>(o) = pk;
+        } else {
+            o[0] = f32_to_bf16(v0);
+            if (n + 1 < p.N) o[1] = f32_to_bf16(v1);
+            if (n + 2 < p.N) o[2] = f32_to_bf16(v2);
+        }
+    } else {
+        float* o = reinterpret_cast<float*>(p.out) + base;
+        if (full) *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
+        else {
+            o[0] = v0;
+            if (n + 1 < p.N) o[1] = v1;
+            if (n + 2 < p.N) o[2] = v2;
+        }
+    }
+}
+
 template <int BN, int WM, int WN, int BK>
 __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
@@ -253,91 +336,19 @@ __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
         }
     }
 
-    // ---- epilogue
+    // ---- epilogue (per-tile, static register indexing only)
     const int hw_out = p.Ho * p.Wo;
 #pragma unroll
     for (int b = 0; b < MI; ++b) {
         const int m = m0 + wm * (BM / WM) + b * 16 + (lane & 15);
-        if (m >= p.M) continue;
-        int orow = m;
-        if (p.o_rowmap) {
-            orow = p.o_rowmap[m];
-            if (orow < 0) continue;
-        }
+        int orow = (m < p.M) ? m : -1;
+        if (orow >= 0 && p.o_rowmap) orow = p.o_rowmap[m];
         float rs = 1.f;
-        if (p.res_scale) rs = p.res_scale[orow / p.rows_per_sample];
+        if (orow >= 0 && p.res_scale) rs = p.res_scale[orow / p.rows_per_sample];
 #pragma unroll
         for (int a = 0; a < NI; ++a) {
             const int n = n0 + wn * (BN / WN) + a * 16 + (lane >> 4) * 4;
-            if (n >= p.N) continue;
-            const bool full = n + 3 < p.N;
-            const size_t base = (size_t)orow * p.ldo + n;
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = acc[a][b][r];
-                if (p.bias && n + r < p.N) t += p.bias[n + r];
-                v[r] = t;
-            }
-            if (p.preact) {
-                if (full) {
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(p.preact + base) = pk;
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) p.preact[base + r] = f32_to_bf16(v[r]);
-                }
-            }
-            if (p.gelu_of) {
-                if (full) {
-                    const uint2 zz = *reinterpret_cast<const uint2*>(p.gelu_of + base);
-                    v[0] *= gelu_grad(bf16_to_f32((uint16_t)(zz.x & 0xffff))); v[1] *= gelu_grad(bf16_to_f32((uint16_t)(zz.x >> 16)));
-                    v[2] *= gelu_grad(bf16_to_f32((uint16_t)(zz.y & 0xffff))); v[3] *= gelu_grad(bf16_to_f32((uint16_t)(zz.y >> 16)));
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] *= gelu_grad(bf16_to_f32(p.gelu_of[base + r]));
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float t = v[r];
-                if (p.act == 1) t = gelu_erf(t);
-                else if (p.act == 2) t = softplus_(t);
-                v[r] = t * rs;
-            }
-            if (p.out_mode == 2) {
-                const int bb = orow / hw_out, pix = orow - bb * hw_out;
-                float* o = reinterpret_cast<float*>(p.out) + ((size_t)bb * p.N + n) * hw_out + pix;
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) o[(size_t)r * hw_out] = v[r];
-                continue;
-            }
-            if (p.res) {
-                if (full) {
-                    const uint2 rv = *reinterpret_cast<const uint2*>(p.res + base);
-                    v[0] += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v[1] += bf16_to_f32((uint16_t)(rv.x >> 16));
-                    v[2] += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v[3] += bf16_to_f32((uint16_t)(rv.y >> 16));
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += bf16_to_f32(p.res[base + r]);
-                }
-            }
-            if (p.out_mode == 0) {
-                uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + base;
-                if (full) {
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(o) = pk;
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = f32_to_bf16(v[r]);
-                }
-            } else {
-                float* o = reinterpret_cast<float*>(p.out) + base;
-                if (full) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-                else
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) o[r] = v[r];
-            }
+            if (orow >= 0) igemm_epilogue_tile(p, acc[a][b], orow, n, rs, hw_out);
         }
     }
 }

@@ -433,10 +433,13 @@ extern "C" int pk_linear_bf16(const void* x, const void* w, void* out, const flo
 }
 
 // ================================================================================================ weight gradient
-// dW[n][t][c] = sum_m G(m, n) * A(m, t, c):  the contraction runs over pixels/tokens m, so both operands are staged
-// TRANSPOSED in LDS ([n][m] and [c][m], 16-byte fragment reads along m).  One workgroup owns a 64(n) x 64(c) tile of
-// one filter tap and one slice of M (split-M over gridDim.z); slices are written to an fp32 workspace and summed in
-// fixed order by k_wgrad_reduce (deterministic, no float atomics).
+// dW[n][t][c] = sum_m G(m, n) * A(m, t, c).  The contraction runs over pixels/tokens m, i.e. along the ROWS of both
+// operands as they sit in HBM, so each MFMA fragment needs 8 consecutive m of one column.  Tiles are staged row-major
+// ([m][n] and [m][c], 16-byte global loads -> 16-byte LDS stores) and the fragments are read with the gfx950 hardware
+// transpose read `ds_read_b64_tr_b16` (4 rows x 16 columns per 16-lane group, delivered column-major): two reads per
+// fragment, no scalar LDS traffic.  Row pitch = width + 16 elements keeps those reads bank-conflict free.
+// One workgroup owns a TN(n) x TC(c) tile of one filter tap and one slice of M (split-M over gridDim.z); slices are
+// written as fp32 slabs and summed in fixed order by k_wgrad_reduce (deterministic, no float atomics).
 struct WgradArgs {
     const uint16_t* x;   // activations (layer input) bf16
     const uint16_t* g;   // output gradient bf16 [rows][N]
@@ -449,68 +452,93 @@ struct WgradArgs {
 };
 
 #define WG_MK 32
-#define WG_PITCH 40
+typedef __attribute__((ext_vector_type(4))) short s16x4;
 
-__global__ void __launch_bounds__(256) k_wgrad(WgradArgs p) {
-    __shared__ __attribute__((aligned(16))) uint16_t sG[2][64 * WG_PITCH];
-    __shared__ __attribute__((aligned(16))) uint16_t sX[2][64 * WG_PITCH];
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int pitch, int col0, int lane) {
+    // fragment for MFMA lane (col = col0 + lane&15, k-group g = lane>>4): elements k = 8g .. 8g+7 of that column
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+    const uint16_t* a0 = tile + (8 * g + q) * pitch + col0 + 4 * pq;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * pitch));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+template <int TN, int TC>   // output tile: TN rows (n) x TC columns (c); 4 waves as 2 x 2
+__global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
+    constexpr int PN = TN + 16, PC = TC + 16;            // LDS row pitches (elements)
+    constexpr int GCH = TN / 8, XCH = TC / 8;            // 16-byte chunks per staged row
+    constexpr int G_PT = WG_MK * GCH / 256, X_PT = WG_MK * XCH / 256;   // chunks per thread per step (1 or 2)
+    constexpr int NI = TN / 2 / 16, CI = TC / 2 / 16;    // accumulator tiles per wave
+    __shared__ __attribute__((aligned(16))) uint16_t sG[2][WG_MK * PN];
+    __shared__ __attribute__((aligned(16))) uint16_t sX[2][WG_MK * PC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = blockIdx.x / p.ctiles, ctile = blockIdx.x - ntile * p.ctiles;
-    const int n0 = ntile * 64, c0 = ctile * 64, t = blockIdx.y;
+    const int n0 = ntile * TN, c0 = ctile * TC, t = blockIdx.y;
     const int kw_n = (p.T == 9) ? 3 : 1, kh = t / kw_n, kw = t - kh * kw_n;
     const int m_begin = blockIdx.z * p.m_per_slice;
     const int m_end = min(p.M, m_begin + p.m_per_slice);
     const bool linear = (p.Ho == 0);
-    const int row = tid & 31, chunk = tid >> 5;   // one 16-byte chunk of G and one of X per thread per step
     const int hw = p.Ho * p.Wo;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.g), 0, 0x7ffffff0, 0x00020000);
 
-    uint4 rg, rx;
-    auto load = [&](int ms) {
-        const int m = ms + row;
-        rg = make_uint4(0, 0, 0, 0);
-        rx = make_uint4(0, 0, 0, 0);
-        if (m >= m_end) return;
-        const int n = n0 + chunk * 8, c = c0 + chunk * 8;
-        if (n < p.N) {
-            const int gr = p.g_rowmap ? p.g_rowmap[m] : m;
-            if (gr >= 0) {
-                rg = *reinterpret_cast<const uint4*>(p.g + (size_t)gr * p.N + n);
-                if (p.g_scale) {
-                    const float sc = p.g_scale[gr / p.g_rows_per_sample];
-                    uint16_t* e = reinterpret_cast<uint16_t*>(&rg);
+    // fixed (row-in-step, chunk) assignment
+    int g_row[G_PT], g_col[G_PT], x_row[X_PT], x_col[X_PT];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16(bf16_to_f32(e[j]) * sc);
+    for (int i = 0; i < G_PT; ++i) { const int q = tid + 256 * i; g_row[i] = q / GCH; g_col[i] = (q % GCH) * 8; }
+#pragma unroll
+    for (int i = 0; i < X_PT; ++i) { const int q = tid + 256 * i; x_row[i] = q / XCH; x_col[i] = (q % XCH) * 8; }
+
+    u32x4 rgv[G_PT], rxv[X_PT];
+    auto load = [&](int ms) {
+#pragma unroll
+        for (int i = 0; i < G_PT; ++i) {
+            const int m = ms + g_row[i], n = n0 + g_col[i];
+            unsigned off = OOB_OFF;
+            float sc = 1.f;
+            if (m < m_end && n < p.N) {
+                const int gr = p.g_rowmap ? p.g_rowmap[m] : m;
+                if (gr >= 0) {
+                    off = (unsigned)((gr * p.N + n) * 2);
+                    if (p.g_scale) sc = p.g_scale[gr / p.g_rows_per_sample];
                 }
             }
-        }
-        if (c < p.Cin) {
-            if (linear) {
-                const int xr = p.a_rowmap ? p.a_rowmap[m] : m;
-                if (xr >= 0) rx = *reinterpret_cast<const uint4*>(p.x + (size_t)xr * p.Cin + c);
-            } else {
-                const int b = m / hw, r = m - b * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
-                const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
-                if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
-                    rx = *reinterpret_cast<const uint4*>(p.x + ((size_t)(b * p.Hs + iy) * p.Ws + ix) * p.Cin + c);
+            rgv[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
+            if (p.g_scale) {
+                uint16_t* e = reinterpret_cast<uint16_t*>(&rgv[i]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16(bf16_to_f32(e[j]) * sc);
             }
+        }
+#pragma unroll
+        for (int i = 0; i < X_PT; ++i) {
+            const int m = ms + x_row[i], c = c0 + x_col[i];
+            unsigned off = OOB_OFF;
+            if (m < m_end && c < p.Cin) {
+                if (linear) {
+                    const int xr = p.a_rowmap ? p.a_rowmap[m] : m;
+                    if (xr >= 0) off = (unsigned)((xr * p.Cin + c) * 2);
+                } else {
+                    const int b = m / hw, r = m - b * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
+                    const int iy = oy * p.stride - p.pad + kh, ix = ox * p.stride - p.pad + kw;
+                    if (iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws) off = (unsigned)((((b * p.Hs + iy) * p.Ws + ix) * p.Cin + c) * 2);
+                }
+            }
+            rxv[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
         }
     };
     auto store = [&](int buf) {
-        const uint16_t* vg = reinterpret_cast<const uint16_t*>(&rg);
-        const uint16_t* vx = reinterpret_cast<const uint16_t*>(&rx);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            sG[buf][(chunk * 8 + j) * WG_PITCH + row] = vg[j];
-            sX[buf][(chunk * 8 + j) * WG_PITCH + row] = vx[j];
-        }
+        for (int i = 0; i < G_PT; ++i) *reinterpret_cast<u32x4*>(&sG[buf][g_row[i] * PN + g_col[i]]) = rgv[i];
+#pragma unroll
+        for (int i = 0; i < X_PT; ++i) *reinterpret_cast<u32x4*>(&sX[buf][x_row[i] * PC + x_col[i]]) = rxv[i];
     };
-    f32x4 acc[2][2];
+    f32x4 acc[NI][CI];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    const int wn = wave >> 1, wc = wave & 1;      // 2 x 2 waves, 32 x 32 each
-    const int frow = lane & 15, fk = (lane >> 4) * 8;
+        for (int b = 0; b < CI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int wn = wave >> 1, wc = wave & 1;
     const int nsteps = (m_end - m_begin + WG_MK - 1) / WG_MK;
     if (nsteps > 0) {
         load(m_begin);
@@ -520,30 +548,30 @@ __global__ void __launch_bounds__(256) k_wgrad(WgradArgs p) {
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         if (s + 1 < nsteps) load(m_begin + (s + 1) * WG_MK);
-        bf16x8 gf[2], xf[2];
+        bf16x8 gf[NI], xf[CI];
 #pragma unroll
-        for (int a = 0; a < 2; ++a) {
-            gf[a] = *reinterpret_cast<const bf16x8*>(&sG[buf][(wn * 32 + a * 16 + frow) * WG_PITCH + fk]);
-            xf[a] = *reinterpret_cast<const bf16x8*>(&sX[buf][(wc * 32 + a * 16 + frow) * WG_PITCH + fk]);
-        }
+        for (int a = 0; a < NI; ++a) gf[a] = tr_frag(sG[buf], PN, wn * (TN / 2) + a * 16, lane);
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int b = 0; b < CI; ++b) xf[b] = tr_frag(sX[buf], PC, wc * (TC / 2) + b * 16, lane);
 #pragma unroll
-            for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < CI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
         if (s + 1 < nsteps) store(buf ^ 1);
         __syncthreads();
     }
     float* dst = p.part + (size_t)blockIdx.z * p.N * p.T * p.Cin;
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < NI; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int c = c0 + wc * 32 + b * 16 + (lane & 15);
-            if (c >= p.Cin) continue;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int n = n0 + wn * 32 + a * 16 + (lane >> 4) * 4 + r;
-                if (n < p.N) dst[((size_t)n * p.T + t) * p.Cin + c] = acc[a][b][r];
+        for (int b = 0; b < CI; ++b) {
+            const int c = c0 + wc * (TC / 2) + b * 16 + (lane & 15);
+            const int n = n0 + wn * (TN / 2) + a * 16 + (lane >> 4) * 4;
+            if (c < p.Cin) {
+                if (n < p.N) dst[((size_t)n * p.T + t) * p.Cin + c] = acc[a][b][0];
+                if (n + 1 < p.N) dst[((size_t)(n + 1) * p.T + t) * p.Cin + c] = acc[a][b][1];
+                if (n + 2 < p.N) dst[((size_t)(n + 2) * p.T + t) * p.Cin + c] = acc[a][b][2];
+                if (n + 3 < p.N) dst[((size_t)(n + 3) * p.T + t) * p.Cin + c] = acc[a][b][3];
             }
         }
 }
@@ -573,9 +601,11 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
+static inline int wgrad_tile(int N, int Cin) { return (N >= 128 && Cin >= 128) ? 128 : 64; }
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
     // enough workgroups to fill 256 CUs several times over (>= 2048), but no slice shorter than 256 rows
-    const int tiles = ((N + 63) / 64) * ((Cin + 63) / 64) * T;
+    const int tl = wgrad_tile(N, Cin);
+    const int tiles = ((N + tl - 1) / tl) * ((Cin + tl - 1) / tl) * T;
     int s = (2048 + tiles - 1) / tiles;
     const int max_s = (M + 255) / 256;
     if (s > max_s) s = max_s;
@@ -600,9 +630,12 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     a.M = M; a.N = N; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = ksize / 2;
     const int S = pk_wgrad_slices(M, N, Cin, a.T);
     a.m_per_slice = ((M + S - 1) / S + WG_MK - 1) / WG_MK * WG_MK;
-    a.ctiles = (Cin + 63) / 64;
+    const int tl = wgrad_tile(N, Cin);
+    a.ctiles = (Cin + tl - 1) / tl;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_wgrad, dim3(((N + 63) / 64) * a.ctiles, a.T, S), dim3(256), 0, st, a);
+    PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
+    if (tl == 128) hipLaunchKernelGGL((k_wgrad2<128, 128>), dim3(((N + 127) / 128) * a.ctiles, a.T, S), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad2<64, 64>), dim3(((N + 63) / 64) * a.ctiles, a.T, S), dim3(256), 0, st, a);
     const int total = N * a.T * Cin;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 15) / 16), dim3(256), 0, st, workspace, dw, S, N, a.T, Cin, out_layout);
     return pk_launch_status("pk_wgrad_bf16");

@@ -232,9 +232,9 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw, save_mean,
                        save_rstd, partial, rows, C, relu, rpb);
     hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0);
-    // dbeta = sum g ; dgamma = sum g*xhat  (copied out of `sums`, which the apply kernel also reads)
-    hipMemcpyAsync(dbeta, sums, C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    hipMemcpyAsync(dgamma, sums + C, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    // dbeta = sum g ; dgamma = sum g*xhat: written to their own destinations (possibly views of the flat gradient buffer)
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(C), dim3(256), 0, st, partial, nb, C, 2 * C, dbeta, 1.f, 0);
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(C), dim3(256), 0, st, partial + C, nb, C, 2 * C, dgamma, 1.f, 0);
     const size_t chunks = (size_t)rows * (C / 8);
     size_t gb = (chunks + 255) / 256;
     if (gb > 4096) gb = 4096;

@@ -42,8 +42,9 @@ class FlatAdamW:
 
     ALIGN = 4            # elements: every tensor starts 16-byte aligned inside the flat buffers
 
-    def __init__(self, model: torch.nn.Module, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01):
+    def __init__(self, model: torch.nn.Module, lr=5e-4, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, direct_grads=False):
         self.model = model
+        self.direct_grads = direct_grads
         named = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
         if not named:
             raise ValueError("model has no trainable parameters")
@@ -97,10 +98,15 @@ class FlatAdamW:
                 fl[o:o + n] &= 0xFD
             self.flags.copy_(fl)
         self._grads_installed = True
+        if self.direct_grads:
+            # backward kernels now store parameter gradients straight into these views (no autograd accumulation)
+            for i, p in enumerate(self.params):
+                p._pk_grad_sink = self.grad_view(i)
 
     def zero_grad(self):
         if self._grads_installed:
-            self.grad.zero_()
+            if not self.direct_grads:          # with the gradient sink every active gradient is overwritten, not accumulated
+                self.grad.zero_()
         else:
             for p in self.params:
                 p.grad = None
@@ -279,7 +285,9 @@ class Trainer:
         t = cfg.train
         if t.optimizer != "AdamW":
             raise ValueError(f"Unknown optimizer: {t.optimizer}")   # the fused kernel implements the reference default only
-        self.opt = FlatAdamW(model, t.lr, tuple(t.betas), 1e-8, t.weight_decay)
+        # gradients are stored directly by the backward kernels unless autograd hooks are needed (eager multi-GPU overlap)
+        world = dist.get_world_size() if dist.is_initialized() else 1
+        self.opt = FlatAdamW(model, t.lr, tuple(t.betas), 1e-8, t.weight_decay, direct_grads=(world == 1 or use_graph))
         self.sched = WarmupMultiStepLR(self.opt, t, iters_per_epoch)
         self.comm = GradientExchange(self.opt, bucket_mb)
         self.comm.broadcast_initial_state()

@@ -29,6 +29,21 @@ def _e(shape, dtype, dev):
     return torch.empty(shape, dtype=dtype, device=dev)
 
 
+# Gradient sink: a parameter may carry `_pk_grad_sink`, an fp32 view of the engine's flat gradient buffer.  Backward kernels
+# then store that parameter's gradient THERE (plain store: every parameter is used once per step) and hand None to autograd,
+# which removes ~800 `grad += g` launches per step.  Set by engine.FlatAdamW(direct_grads=True); absent = ordinary autograd.
+def grad_sink_of(param):
+    return getattr(param, "_pk_grad_sink", None)
+
+
+def _sink(param):
+    """-> (destination tensor, direct?) for the gradient of `param`."""
+    dst = grad_sink_of(param)
+    if dst is not None:
+        return dst, True
+    return _e(tuple(param.shape), F32, param.device), False
+
+
 def _up8(n):
     return -(-n // 8) * 8
 
@@ -177,8 +192,8 @@ def _conv_dgrad(g, wd, Cin, ksize, stride, in_hw):
     return dx
 
 
-def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=None, g_rps=0, M=None, oihw=True):
-    """-> fp32 gradient (N, Cin, k, k) for conv (geom=(B,Hs,Ws,Ho,Wo)) or (N, Cin) for linear (geom=None)."""
+def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=None, g_rps=0, M=None, oihw=True, out=None):
+    """-> fp32 gradient (N, Cin, k, k) for conv (geom=(B,Hs,Ws,Ho,Wo)) or (N, Cin) for linear (geom=None); `out` = destination."""
     T = ksize * ksize
     if geom is None:
         B = Hs = Ws = Ho = Wo = 0
@@ -187,16 +202,16 @@ def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=No
         M = B * Ho * Wo
     S = _lib.lib.pk_wgrad_slices(M, N, Cin, T)
     ws = _e((S * N * T * Cin,), F32, x.device)
-    dw = _e((N, Cin, ksize, ksize) if geom is not None else (N, Cin), F32, x.device)
+    dw = out if out is not None else _e((N, Cin, ksize, ksize) if geom is not None else (N, Cin), F32, x.device)
     call("pk_wgrad_bf16", x, g, ws, dw, a_map, g_map, g_scale, g_rps, M, N, Cin, ksize, stride, B, Hs, Ws, Ho, Wo,
          1 if (geom is not None and oihw) else 0, stream_ptr())
     return dw
 
 
-def _colsum(g, rows, N, rowmap=None, row_scale=None, rps=0):
+def _colsum(g, rows, N, rowmap=None, row_scale=None, rps=0, out=None):
     nb = _lib.lib.pk_ln_bwd_blocks(rows)
     part = _e((nb, N), F32, g.device)
-    out = _e((N,), F32, g.device)
+    out = out if out is not None else _e((N,), F32, g.device)
     call("pk_colsum_bf16", g, rowmap, row_scale, rps, part, out, rows, N, stream_ptr())
     return out
 
@@ -205,6 +220,7 @@ def _colsum(g, rows, N, rowmap=None, row_scale=None, rps=0):
 class _ConvBnAct(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, gamma, beta, residual, bn, stride, relu, training):
+        ctx.params = (weight, gamma, beta)
         wc = _wc()
         wf, wd = wc.fwd[id(weight)], wc.dgrad[id(weight)]
         Cout, Cin_real, ksize = weight.shape[0], weight.shape[1], weight.shape[2]
@@ -239,16 +255,24 @@ class _ConvBnAct(torch.autograd.Function):
         dev, Cout, Cin, M = dy.device, raw.shape[-1], x.shape[-1], B * Ho * Wo
         dy = dy.contiguous()
         nb = _lib.lib.pk_bn_bwd_blocks(M)
+        w_p, g_p, b_p = ctx.params
         part, sums = _e((nb, 2, Cout), F32, dev), _e((2 * Cout,), F32, dev)
-        dgamma, dbeta = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
+        (dgamma, sg), (dbeta, sb) = _sink(g_p), _sink(b_p)
         draw = _e(raw.shape, BF16, dev)
         dres = _e(raw.shape, BF16, dev) if has_res else None
         call("pk_bn_bwd", dy, y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, dres, M, Cout, 1 if relu else 0, stream_ptr())
         dx = _conv_dgrad(draw, wd, Cin, ksize, stride, (Hs, Ws)) if ctx.needs_input_grad[0] else None
-        dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo))
-        if Cin != Cin_real:
-            dw = dw[:, :Cin_real].contiguous()
-        return dx, dw, dgamma, dbeta, dres, None, None, None, None
+        if Cin != Cin_real:                # stem: 3 real input channels inside 8-channel pixels
+            dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo))[:, :Cin_real].contiguous()
+            dst = grad_sink_of(w_p)
+            if dst is not None:
+                dst.copy_(dw)
+                dw = None
+        else:
+            dst, sw = _sink(w_p)
+            dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo), out=dst)
+            dw = None if sw else dw
+        return dx, dw, None if sg else dgamma, None if sb else dbeta, dres, None, None, None, None
 
 
 def conv_bn_act(x, conv, bn, relu=False, residual=None, training=False):
@@ -259,6 +283,7 @@ def conv_bn_act(x, conv, bn, relu=False, residual=None, training=False):
 class _HeadOut(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, softplus):
+        ctx.params = (weight, bias)
         wc = _wc()
         wf, wd = wc.fwd[id(weight)], wc.dgrad[id(weight)]
         x = x.contiguous()
@@ -280,9 +305,15 @@ class _HeadOut(torch.autograd.Function):
         call("pk_nchw_f32_to_nhwc_bf16", dout.contiguous(), y if softplus else None, g, B, N, H, W, Np, stream_ptr())
         dx = _e((B, H, W, Cin), BF16, x.device)
         call("pk_conv2d_nhwc", g, wd, dx, None, None, B, H, W, Np, Cin, 1, 1, 0, H, W, 0, 0, stream_ptr())
-        dw = _wgrad(x, g, Np, Cin, 1, 1, (B, H, W, H, W))[:N].contiguous()
-        db = _colsum(g, B * H * W, Np)[:N].contiguous()
-        return dx, dw, db, None
+        w_p, b_p = ctx.params
+        dw = _wgrad(x, g, Np, Cin, 1, 1, (B, H, W, H, W))[:N]
+        db = _colsum(g, B * H * W, Np)[:N]
+        dst_w, dst_b = grad_sink_of(w_p), grad_sink_of(b_p)
+        if dst_w is not None and dst_b is not None:
+            dst_w.copy_(dw)
+            dst_b.copy_(db)
+            return dx, None, None, None
+        return dx, dw.contiguous(), db.contiguous(), None
 
 
 def head_out(x, conv, softplus=False):
@@ -318,14 +349,15 @@ def _layernorm(x2d, gamma, beta):
     return y, mean, rstd
 
 
-def _layernorm_bwd(dy, x2d, mean, rstd, gamma, dres):
+def _layernorm_bwd(dy, x2d, mean, rstd, gamma, dres, g_param=None, b_param=None):
     M, C = x2d.shape
     nb = _lib.lib.pk_ln_bwd_blocks(M)
     part = _e((nb, 2, C), F32, x2d.device)
     dx = _e((M, C), BF16, x2d.device)
-    dg, db = _e((C,), F32, x2d.device), _e((C,), F32, x2d.device)
+    (dg, sg) = _sink(g_param) if g_param is not None else (_e((C,), F32, x2d.device), False)
+    (db, sb) = _sink(b_param) if b_param is not None else (_e((C,), F32, x2d.device), False)
     call("pk_layernorm_bwd", dy, x2d, mean, rstd, gamma, dres, dx, part, dg, db, M, C, stream_ptr())
-    return dx, dg, db
+    return dx, (None if sg else dg), (None if sb else db)
 
 
 def _linear(x, w, out_rows, N, K, bias=None, residual=None, res_scale=None, a_map=None, o_map=None, preact=None, gelu_of=None,
@@ -341,6 +373,7 @@ class _AttnHalf(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, g1, b1, table, wqkv, bqkv, wproj, bproj, scale1, heads):
+        ctx.params = (g1, b1, table, wqkv, bqkv, wproj, bproj)
         wc = _wc()
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -369,20 +402,26 @@ class _AttnHalf(torch.autograd.Function):
         dev = dy.device
         dy2 = dy.contiguous().view(M, C)
         # proj: rows of the GEMM are window-order tokens, dy rows are gathered through the map; DropPath scale per sample
+        pg1, pb1, ptab, pwqkv, pbqkv, pwproj, pbproj = ctx.params
         d_o = _linear(dy2, wproj_t, Mw, C, C, res_scale=s1, a_map=amap, rps=nwin * WS * WS)
-        dwproj = _wgrad(o, dy2, C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw)
-        dbproj = _colsum(dy2, M, C, row_scale=s1, rps=H * W)
+        dst, s_wp = _sink(pwproj)
+        dwproj = _wgrad(o, dy2, C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw, out=dst)
+        dst, s_bp = _sink(pbproj)
+        dbproj = _colsum(dy2, M, C, row_scale=s1, rps=H * W, out=dst)
         # attention core
         dqkv = _e((Mw, 3 * C), BF16, dev)
         part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads),), F32, dev)
-        dtable = _e(tuple(table.shape), F32, dev)
+        dtable, s_t = _sink(ptab)
         call("pk_window_attn_bwd", qkv, table, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, stream_ptr())
         # qkv linear: scatter the token gradients back to pixel rows (pad tokens dropped)
         du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
-        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw)
-        dbqkv = _colsum(dqkv, Mw, 3 * C)
-        dx, dg1, db1 = _layernorm_bwd(du, x2, mean, rstd, g1, dy2)
-        return dx.view(B, H, W, C), dg1, db1, dtable, dwqkv, dbqkv, dwproj, dbproj, None, None
+        dst, s_wq = _sink(pwqkv)
+        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw, out=dst)
+        dst, s_bq = _sink(pbqkv)
+        dbqkv = _colsum(dqkv, Mw, 3 * C, out=dst)
+        dx, dg1, db1 = _layernorm_bwd(du, x2, mean, rstd, g1, dy2, pg1, pb1)
+        return (dx.view(B, H, W, C), dg1, db1, None if s_t else dtable, None if s_wq else dwqkv, None if s_bq else dbqkv,
+                None if s_wp else dwproj, None if s_bp else dbproj, None, None)
 
 
 class _MlpHalf(torch.autograd.Function):
@@ -390,6 +429,7 @@ class _MlpHalf(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, g2, b2, w1, bias1, w2, bias2, scale2):
+        ctx.params = (g2, b2, w1, bias1, w2, bias2)
         wc = _wc()
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -411,14 +451,20 @@ class _MlpHalf(torch.autograd.Function):
         s2 = s2 if has_s else None
         M = B * H * W
         dy2 = dy.contiguous().view(M, C)
+        pg2, pb2, pw1, pbias1, pw2, pbias2 = ctx.params
         dz = _linear(dy2, w2_t, M, Hd, C, res_scale=s2, gelu_of=z, rps=H * W)        # (dy W2) * s2 * gelu'(z)
-        dw2 = _wgrad(h, dy2, C, Hd, 1, 1, None, g_scale=s2, g_rps=H * W, M=M)
-        db2 = _colsum(dy2, M, C, row_scale=s2, rps=H * W)
+        dst, s_w2 = _sink(pw2)
+        dw2 = _wgrad(h, dy2, C, Hd, 1, 1, None, g_scale=s2, g_rps=H * W, M=M, out=dst)
+        dst, s_b2 = _sink(pbias2)
+        db2 = _colsum(dy2, M, C, row_scale=s2, rps=H * W, out=dst)
         dv = _linear(dz, w1_t, M, C, Hd)
-        dw1 = _wgrad(v, dz, Hd, C, 1, 1, None, M=M)
-        db1 = _colsum(dz, M, Hd)
-        dx, dg2, dbt2 = _layernorm_bwd(dv, x2, mean, rstd, g2, dy2)
-        return dx.view(B, H, W, C), dg2, dbt2, dw1, db1, dw2, db2, None
+        dst, s_w1 = _sink(pw1)
+        dw1 = _wgrad(v, dz, Hd, C, 1, 1, None, M=M, out=dst)
+        dst, s_b1 = _sink(pbias1)
+        db1 = _colsum(dz, M, Hd, out=dst)
+        dx, dg2, dbt2 = _layernorm_bwd(dv, x2, mean, rstd, g2, dy2, pg2, pb2)
+        return (dx.view(B, H, W, C), dg2, dbt2, None if s_w1 else dw1, None if s_b1 else db1, None if s_w2 else dw2,
+                None if s_b2 else db2, None)
 
 
 def window_block(x, blk, heads, scale1=None, scale2=None):

@@ -19,24 +19,28 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 __device__ __forceinline__ bf16x8 lds_frag(const uint16_t* base, int row, int pitch, int k0) {
     return *reinterpret_cast<const bf16x8*>(base + row * pitch + k0);
 }
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+// Fragment whose 8 k-values run down the ROWS of a row-major LDS tile (k0 .. k0+31 = rows, col0 + lane&15 = column):
+// two gfx950 transpose reads (ds_read_b64_tr_b16: 4 rows x 16 columns per 16-lane group, delivered column-major).
+__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int pitch, int k0, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+    const uint16_t* a0 = tile + (k0 + 8 * g + q) * pitch + col0 + 4 * pq;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * pitch));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 __device__ __forceinline__ int rel_index(int i, int j) {
     const int yi = i / AT_WS, xi = i - yi * AT_WS, yj = j / AT_WS, xj = j - yj * AT_WS;
     return (yi - yj + AT_WS - 1) * (2 * AT_WS - 1) + (xi - xj + AT_WS - 1);
 }
 
-// Load a [49][d] slice (row stride ld) into a zero-padded [64][RP] row-major LDS tile and optionally its transpose [32][TP].
-__device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ g, int ld, int d, uint16_t* rowmajor, uint16_t* transposed,
-                                           int lane) {
+// Load a [49][d] slice (row stride ld) into a zero-padded [64][RP] row-major LDS tile (rows >= 49 and channels >= d are zero).
+__device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ g, int ld, int d, uint16_t* rowmajor, int lane) {
     for (int idx = lane; idx < 64 * 4; idx += 64) {
         const int row = idx >> 2, ch = idx & 3;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (row < AT_N && ch * 8 < d) v = *reinterpret_cast<const uint4*>(g + (size_t)row * ld + ch * 8);
-        if (rowmajor) *reinterpret_cast<uint4*>(rowmajor + row * RP + ch * 8) = v;
-        if (transposed) {
-            const uint16_t* e = reinterpret_cast<const uint16_t*>(&v);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) transposed[(ch * 8 + j) * TP + row] = e[j];
-        }
+        *reinterpret_cast<uint4*>(rowmajor + row * RP + ch * 8) = v;
     }
 }
 
@@ -44,14 +48,14 @@ __device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ g, int l
 __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict__ qkv, const float* __restrict__ table,
                                                      uint16_t* __restrict__ out, float* __restrict__ lse, int heads, int C, int d,
                                                      float scale) {
-    __shared__ __attribute__((aligned(16))) uint16_t sQ[64 * RP], sK[64 * RP], sVt[32 * TP], sP[64 * TP];
+    __shared__ __attribute__((aligned(16))) uint16_t sQ[64 * RP], sK[64 * RP], sV[64 * RP], sP[64 * TP];
     __shared__ float sBias[176];
     const int lane = threadIdx.x, g4 = lane >> 4, l16 = lane & 15;
     const int w = blockIdx.x / heads, h = blockIdx.x - w * heads;
     const uint16_t* base = qkv + (size_t)w * AT_N * 3 * C + h * d;
-    stage_tile(base, 3 * C, d, sQ, nullptr, lane);
-    stage_tile(base + C, 3 * C, d, sK, nullptr, lane);
-    stage_tile(base + 2 * C, 3 * C, d, nullptr, sVt, lane);
+    stage_tile(base, 3 * C, d, sQ, lane);
+    stage_tile(base + C, 3 * C, d, sK, lane);
+    stage_tile(base + 2 * C, 3 * C, d, sV, lane);
     for (int i = lane; i < 169; i += 64) sBias[i] = table[i * heads + h];
     __syncthreads();
 
@@ -100,15 +104,15 @@ __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict_
     }
     __syncthreads();
 
-    // O = P V : A = P rows i (k = j), B = V^T rows e (k = j)
+    // O = P V : A = P rows i (k = j); B[k=j][col=e] = V[j][e] read with the transpose read from the row-major V tile
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
         const bf16x8 p0 = lds_frag(sP, 16 * ci + l16, TP, g4 * 8), p1 = lds_frag(sP, 16 * ci + l16, TP, 32 + g4 * 8);
 #pragma unroll
         for (int ce = 0; ce < 2; ++ce) {
             if (ce * 16 >= d) break;
-            f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, lds_frag(sVt, 16 * ce + l16, TP, g4 * 8), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, lds_frag(sVt, 16 * ce + l16, TP, 32 + g4 * 8), o, 0, 0, 0);
+            f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, tr_frag(sV, RP, 0, 16 * ce, lane), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, tr_frag(sV, RP, 32, 16 * ce, lane), o, 0, 0, 0);
             const int e = 16 * ce + l16;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -139,8 +143,7 @@ __global__ void __launch_bounds__(64) k_win_attn_bwd(const uint16_t* __restrict_
                                                      uint16_t* __restrict__ dqkv, float* __restrict__ dbias_part, int n_windows, int heads,
                                                      int C, int d, float scale, int wstride) {
     __shared__ __attribute__((aligned(16))) uint16_t sQ[64 * RP], sK[64 * RP], sV[64 * RP], sdO[64 * RP];
-    __shared__ __attribute__((aligned(16))) uint16_t sQt[32 * TP], sKt[32 * TP], sdOt[32 * TP];
-    __shared__ __attribute__((aligned(16))) uint16_t sPt[64 * TP], sdS[64 * TP], sdSt[64 * TP];
+    __shared__ __attribute__((aligned(16))) uint16_t sP[64 * TP], sdS[64 * TP];     // row-major [i][j]; transposes come from tr reads
     __shared__ float sBias[176];
     const int lane = threadIdx.x, g4 = lane >> 4, l16 = lane & 15;
     const int h = blockIdx.x % heads;
@@ -154,10 +157,10 @@ __global__ void __launch_bounds__(64) k_win_attn_bwd(const uint16_t* __restrict_
     for (int w = blockIdx.x / heads; w < n_windows; w += wstride) {
         __syncthreads();   // previous iteration's LDS reads are done
         const uint16_t* base = qkv + (size_t)w * AT_N * 3 * C + h * d;
-        stage_tile(base, 3 * C, d, sQ, sQt, lane);
-        stage_tile(base + C, 3 * C, d, sK, sKt, lane);
-        stage_tile(base + 2 * C, 3 * C, d, sV, nullptr, lane);
-        stage_tile(dout + (size_t)w * AT_N * C + h * d, C, d, sdO, sdOt, lane);
+        stage_tile(base, 3 * C, d, sQ, lane);
+        stage_tile(base + C, 3 * C, d, sK, lane);
+        stage_tile(base + 2 * C, 3 * C, d, sV, lane);
+        stage_tile(dout + (size_t)w * AT_N * C + h * d, C, d, sdO, lane);
         __syncthreads();
 
         bf16x8 qf[4], kf[4], vf[4], of[4];
@@ -195,31 +198,30 @@ __global__ void __launch_bounds__(64) k_win_attn_bwd(const uint16_t* __restrict_
                     const int j = 16 * cj + l16;
                     const float ds = p[cj] * (dp[cj][r] - delta);
                     dsum[ci][cj][r] += ds;
-                    const uint16_t pb = f32_to_bf16(p[cj]), db = f32_to_bf16(ds);
-                    sPt[j * TP + i] = pb;
-                    sdS[i * TP + j] = db;
-                    sdSt[j * TP + i] = db;
+                    sP[i * TP + j] = f32_to_bf16(p[cj]);
+                    sdS[i * TP + j] = f32_to_bf16(ds);
                 }
             }
         }
         __syncthreads();
         uint16_t* dq = dqkv + (size_t)w * AT_N * 3 * C + h * d;
-        // dV = P^T dO ; dK = scale * dS^T Q  (rows j) ; dQ = scale * dS K (rows i)
+        // dV = P^T dO, dK = scale * dS^T Q (output rows j: A operands are transpose reads of the row-major P / dS tiles);
+        // dQ = scale * dS K (output rows i: plain row fragments of dS).  B operands Q / K / dO: transpose reads (k runs down rows).
 #pragma unroll
         for (int ct = 0; ct < 4; ++ct) {
-            const bf16x8 pt0 = lds_frag(sPt, 16 * ct + l16, TP, g4 * 8), pt1 = lds_frag(sPt, 16 * ct + l16, TP, 32 + g4 * 8);
-            const bf16x8 st0 = lds_frag(sdSt, 16 * ct + l16, TP, g4 * 8), st1 = lds_frag(sdSt, 16 * ct + l16, TP, 32 + g4 * 8);
+            const bf16x8 pt0 = tr_frag(sP, TP, 0, 16 * ct, lane), pt1 = tr_frag(sP, TP, 32, 16 * ct, lane);
+            const bf16x8 st0 = tr_frag(sdS, TP, 0, 16 * ct, lane), st1 = tr_frag(sdS, TP, 32, 16 * ct, lane);
             const bf16x8 ds0 = lds_frag(sdS, 16 * ct + l16, TP, g4 * 8), ds1 = lds_frag(sdS, 16 * ct + l16, TP, 32 + g4 * 8);
 #pragma unroll
             for (int ce = 0; ce < 2; ++ce) {
                 if (ce * 16 >= d) break;
                 const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pt0, lds_frag(sdOt, 16 * ce + l16, TP, g4 * 8), z, 0, 0, 0);
-                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pt1, lds_frag(sdOt, 16 * ce + l16, TP, 32 + g4 * 8), dv, 0, 0, 0);
-                f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st0, lds_frag(sQt, 16 * ce + l16, TP, g4 * 8), z, 0, 0, 0);
-                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st1, lds_frag(sQt, 16 * ce + l16, TP, 32 + g4 * 8), dk, 0, 0, 0);
-                f32x4 dqa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ds0, lds_frag(sKt, 16 * ce + l16, TP, g4 * 8), z, 0, 0, 0);
-                dqa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ds1, lds_frag(sKt, 16 * ce + l16, TP, 32 + g4 * 8), dqa, 0, 0, 0);
+                f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pt0, tr_frag(sdO, RP, 0, 16 * ce, lane), z, 0, 0, 0);
+                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pt1, tr_frag(sdO, RP, 32, 16 * ce, lane), dv, 0, 0, 0);
+                f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st0, tr_frag(sQ, RP, 0, 16 * ce, lane), z, 0, 0, 0);
+                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st1, tr_frag(sQ, RP, 32, 16 * ce, lane), dk, 0, 0, 0);
+                f32x4 dqa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ds0, tr_frag(sK, RP, 0, 16 * ce, lane), z, 0, 0, 0);
+                dqa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ds1, tr_frag(sK, RP, 32, 16 * ce, lane), dqa, 0, 0, 0);
                 const int e = 16 * ce + l16;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {

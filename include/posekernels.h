@@ -131,12 +131,14 @@ int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, c
                    const int32_t* a_rowmap, const int32_t* o_rowmap, void* preact_out, const void* gelu_grad_of,
                    int M, int N, int K, int rows_per_sample, int act, int out_fp32, void* stream);
 
-/* weight gradient of either form: dw = sum_m grad_out[m]^T (x) A(m); workspace = pk_wgrad_slices(...)*N*k*k*Cin floats.
- * out_layout 0: [N][k*k][Cin]; 1: OIHW (the reference's nn.Conv2d.weight layout).  Ho == 0 selects the linear form.   */
+/* weight gradient of either form: dw = sum_m grad_out[m]^T (x) A(m); workspace = pk_wgrad_slices(...)*N*(k*k*Cin + 1) floats.
+ * out_layout 0: [N][k*k][Cin]; 1: OIHW (the reference's nn.Conv2d.weight layout).  Ho == 0 selects the linear form.
+ * dbias (optional, n_bias <= N entries): the bias gradient = column sums of the same (gathered, scaled) grad_out rows,
+ * accumulated from the tile already staged in LDS.                                                                       */
 int pk_wgrad_slices(int M, int N, int Cin, int T);
-int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, const int32_t* a_rowmap,
-                  const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M, int N, int Cin, int ksize,
-                  int stride, int B, int Hs, int Ws, int Ho, int Wo, int out_layout, void* stream);
+int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, float* dbias, int n_bias,
+                  const int32_t* a_rowmap, const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M, int N,
+                  int Cin, int ksize, int stride, int B, int Hs, int Ws, int Ho, int Wo, int out_layout, void* stream);
 
 /* window attention core (models/hrformer.py:183-196): softmax(scale*q k^T + table[index]) v per (window, head);
  * qkv (n_windows*49, 3C) bf16 in the reference's channel order s*C + h*d + e; rel_table (169, heads) fp32.          */

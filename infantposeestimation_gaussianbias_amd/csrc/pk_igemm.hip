@@ -448,6 +448,7 @@ struct WgradArgs {
     const int32_t* g_rowmap;  // source row of g for GEMM row m, -1 = zero row
     const float* g_scale;     // optional per-sample multiplier of g rows (DropPath), indexed by g_row / g_rows_per_sample
     int g_rows_per_sample;
+    float* bias_part;         // optional [S][N] fp32: column sums of the (scaled, gathered) G rows = bias gradient slabs
     int M, N, Cin, T, Hs, Ws, Ho, Wo, stride, pad, m_per_slice, ctiles;
 };
 
@@ -540,6 +541,8 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
         for (int b = 0; b < CI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wn = wave >> 1, wc = wave & 1;
     const int nsteps = (m_end - m_begin + WG_MK - 1) / WG_MK;
+    const bool do_bias = p.bias_part && ctile == 0 && t == 0;      // one workgroup column per n-tile owns the bias slab
+    float bsum = 0.f;
     if (nsteps > 0) {
         load(m_begin);
         store(0);
@@ -548,6 +551,10 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         if (s + 1 < nsteps) load(m_begin + (s + 1) * WG_MK);
+        if (do_bias && tid < TN) {          // column tid of the staged G tile: 32 rows, fixed order
+#pragma unroll 8
+            for (int r = 0; r < WG_MK; ++r) bsum += bf16_to_f32(sG[buf][r * PN + tid]);
+        }
         bf16x8 gf[NI], xf[CI];
 #pragma unroll
         for (int a = 0; a < NI; ++a) gf[a] = tr_frag(sG[buf], PN, wn * (TN / 2) + a * 16, lane);
@@ -560,6 +567,7 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
         if (s + 1 < nsteps) store(buf ^ 1);
         __syncthreads();
     }
+    if (do_bias && tid < TN && n0 + tid < p.N) p.bias_part[(size_t)blockIdx.z * p.N + n0 + tid] = bsum;
     float* dst = p.part + (size_t)blockIdx.z * p.N * p.T * p.Cin;
 #pragma unroll
     for (int a = 0; a < NI; ++a)
@@ -580,10 +588,25 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
 // Block = 16 elements x 16 slice-lanes (lane r sums slices s = r mod 16, fixed-order combine): short dependency chains
 // even with hundreds of slices, still deterministic.
 __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ part, float* __restrict__ out, int S, int N, int T,
-                                                      int Cin, int layout) {
+                                                      int Cin, int layout, const float* __restrict__ bias_part, float* __restrict__ dbias,
+                                                      int n_bias, int w_blocks) {
     __shared__ float sh[16][17];
-    const int total = N * T * Cin;
     const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    if ((int)blockIdx.x >= w_blocks) {          // trailing blocks: bias-gradient slabs [S][N] -> dbias[0..n_bias)
+        const int n = (blockIdx.x - w_blocks) * 16 + col;
+        float s = 0.f;
+        if (n < n_bias)
+            for (int k = rl; k < S; k += 16) s += bias_part[(size_t)k * N + n];
+        sh[rl][col] = s;
+        __syncthreads();
+        if (rl != 0 || n >= n_bias) return;
+        s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += sh[r][col];
+        dbias[n] = s;
+        return;
+    }
+    const int total = N * T * Cin;
     const int i = blockIdx.x * 16 + col;
     float s = 0.f;
     if (i < total)
@@ -614,9 +637,10 @@ extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
     return s;
 }
 
-extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, const int32_t* a_rowmap,
-                             const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M, int N, int Cin, int ksize,
-                             int stride, int B, int Hs, int Ws, int Ho, int Wo, int out_layout, void* stream) {
+extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, float* dbias, int n_bias,
+                             const int32_t* a_rowmap, const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M,
+                             int N, int Cin, int ksize, int stride, int B, int Hs, int Ws, int Ho, int Wo, int out_layout,
+                             void* stream) {
     PK_REQUIRE(x && grad_out && workspace && dw, "pk_wgrad_bf16: null pointer");
     PK_REQUIRE(M > 0 && N > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "pk_wgrad_bf16: bad sizes");
     PK_SUPPORTED((Cin & 7) == 0 && (N & 7) == 0, "pk_wgrad_bf16: Cin=%d and N=%d must be multiples of 8", Cin, N);
@@ -629,6 +653,8 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     a.g_scale = g_scale; a.g_rows_per_sample = g_rows_per_sample > 0 ? g_rows_per_sample : 1;
     a.M = M; a.N = N; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = ksize / 2;
     const int S = pk_wgrad_slices(M, N, Cin, a.T);
+    PK_REQUIRE(!dbias || (n_bias > 0 && n_bias <= N), "pk_wgrad_bf16: n_bias");
+    a.bias_part = dbias ? workspace + (size_t)S * N * a.T * Cin : nullptr;     // bias slabs follow the weight slabs
     a.m_per_slice = ((M + S - 1) / S + WG_MK - 1) / WG_MK * WG_MK;
     const int tl = wgrad_tile(N, Cin);
     a.ctiles = (Cin + tl - 1) / tl;
@@ -637,6 +663,8 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     if (tl == 128) hipLaunchKernelGGL((k_wgrad2<128, 128>), dim3(((N + 127) / 128) * a.ctiles, a.T, S), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad2<64, 64>), dim3(((N + 63) / 64) * a.ctiles, a.T, S), dim3(256), 0, st, a);
     const int total = N * a.T * Cin;
-    hipLaunchKernelGGL(k_wgrad_reduce, dim3((total + 15) / 16), dim3(256), 0, st, workspace, dw, S, N, a.T, Cin, out_layout);
+    const int w_blocks = (total + 15) / 16, b_blocks = dbias ? (n_bias + 15) / 16 : 0;
+    hipLaunchKernelGGL(k_wgrad_reduce, dim3(w_blocks + b_blocks), dim3(256), 0, st, workspace, dw, S, N, a.T, Cin, out_layout,
+                       a.bias_part, dbias, n_bias, w_blocks);
     return pk_launch_status("pk_wgrad_bf16");
 }

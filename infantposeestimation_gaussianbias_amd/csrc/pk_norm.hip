@@ -24,7 +24,8 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 // out[k] (+)= scale * sum_b partial[b*stride + k], k < K.  Block = 16 columns x 16 row-lanes: lane r sums rows b = r (mod 16),
 // the 16 lane sums are combined in fixed order -> deterministic, and the serial chain is nb/16 instead of nb.
 __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ part, int nb, int K, int stride, float* __restrict__ out,
-                                                      float scale, int accumulate) {
+                                                      float scale, int accumulate, float* __restrict__ out_lo = nullptr,
+                                                      float* __restrict__ out_hi = nullptr, int split = 0) {
     __shared__ double sh[16][17];
     const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int k = blockIdx.x * 16 + col;
@@ -38,7 +39,9 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ 
 #pragma unroll
         for (int r = 0; r < 16; ++r) t += sh[r][col];
         const float v = (float)t * scale;
-        out[k] = accumulate ? out[k] + v : v;
+        if (out) out[k] = accumulate ? out[k] + v : v;
+        if (out_lo && k < split) out_lo[k] = v;            // optional second copy, split into two destinations
+        if (out_hi && k >= split) out_hi[k - split] = v;
     }
 }
 #define SUM_PARTIALS_GRID(K) dim3(((K) + 15) / 16)
@@ -231,10 +234,8 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     const int rpb = (int)((rows + nb - 1) / nb);
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw, save_mean,
                        save_rstd, partial, rows, C, relu, rpb);
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0);
-    // dbeta = sum g ; dgamma = sum g*xhat: written to their own destinations (possibly views of the flat gradient buffer)
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(C), dim3(256), 0, st, partial, nb, C, 2 * C, dbeta, 1.f, 0);
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(C), dim3(256), 0, st, partial + C, nb, C, 2 * C, dgamma, 1.f, 0);
+    // sums = [sum g | sum g*xhat] for the apply kernel; the same values go to dbeta / dgamma (possibly flat-gradient views)
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0, dbeta, dgamma, C);
     const size_t chunks = (size_t)rows * (C / 8);
     size_t gb = (chunks + 255) / 256;
     if (gb > 4096) gb = 4096;
@@ -427,8 +428,8 @@ extern "C" int pk_layernorm_bwd(const void* dy, const void* x, const float* save
         default: LNB(64); break;
     }
 #undef LNB
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(C), dim3(256), 0, st, partial, nb, C, 2 * C, dgamma, 1.f, 0);
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(C), dim3(256), 0, st, partial + C, nb, C, 2 * C, dbeta, 1.f, 0);
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, (float*)nullptr, 1.f, 0, dgamma,
+                       dbeta, C);
     return pk_launch_status("pk_layernorm_bwd");
 }
 

@@ -192,8 +192,10 @@ def _conv_dgrad(g, wd, Cin, ksize, stride, in_hw):
     return dx
 
 
-def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=None, g_rps=0, M=None, oihw=True, out=None):
-    """-> fp32 gradient (N, Cin, k, k) for conv (geom=(B,Hs,Ws,Ho,Wo)) or (N, Cin) for linear (geom=None); `out` = destination."""
+def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=None, g_rps=0, M=None, oihw=True, out=None,
+           dbias=None):
+    """-> fp32 gradient (N, Cin, k, k) for conv (geom=(B,Hs,Ws,Ho,Wo)) or (N, Cin) for linear (geom=None); `out` = destination.
+    `dbias` (fp32, <= N entries) additionally receives the bias gradient (column sums of the same scaled/gathered rows)."""
     T = ksize * ksize
     if geom is None:
         B = Hs = Ws = Ho = Wo = 0
@@ -201,10 +203,10 @@ def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=No
         B, Hs, Ws, Ho, Wo = geom
         M = B * Ho * Wo
     S = _lib.lib.pk_wgrad_slices(M, N, Cin, T)
-    ws = _e((S * N * T * Cin,), F32, x.device)
+    ws = _e((S * N * (T * Cin + 1),), F32, x.device)
     dw = out if out is not None else _e((N, Cin, ksize, ksize) if geom is not None else (N, Cin), F32, x.device)
-    call("pk_wgrad_bf16", x, g, ws, dw, a_map, g_map, g_scale, g_rps, M, N, Cin, ksize, stride, B, Hs, Ws, Ho, Wo,
-         1 if (geom is not None and oihw) else 0, stream_ptr())
+    call("pk_wgrad_bf16", x, g, ws, dw, dbias, 0 if dbias is None else dbias.numel(), a_map, g_map, g_scale, g_rps, M, N, Cin, ksize,
+         stride, B, Hs, Ws, Ho, Wo, 1 if (geom is not None and oihw) else 0, stream_ptr())
     return dw
 
 
@@ -306,8 +308,8 @@ class _HeadOut(torch.autograd.Function):
         dx = _e((B, H, W, Cin), BF16, x.device)
         call("pk_conv2d_nhwc", g, wd, dx, None, None, B, H, W, Np, Cin, 1, 1, 0, H, W, 0, 0, stream_ptr())
         w_p, b_p = ctx.params
-        dw = _wgrad(x, g, Np, Cin, 1, 1, (B, H, W, H, W))[:N]
-        db = _colsum(g, B * H * W, Np)[:N]
+        db = _e((N,), F32, x.device)
+        dw = _wgrad(x, g, Np, Cin, 1, 1, (B, H, W, H, W), dbias=db)[:N]
         dst_w, dst_b = grad_sink_of(w_p), grad_sink_of(b_p)
         if dst_w is not None and dst_b is not None:
             dst_w.copy_(dw)
@@ -405,9 +407,8 @@ class _AttnHalf(torch.autograd.Function):
         pg1, pb1, ptab, pwqkv, pbqkv, pwproj, pbproj = ctx.params
         d_o = _linear(dy2, wproj_t, Mw, C, C, res_scale=s1, a_map=amap, rps=nwin * WS * WS)
         dst, s_wp = _sink(pwproj)
-        dwproj = _wgrad(o, dy2, C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw, out=dst)
-        dst, s_bp = _sink(pbproj)
-        dbproj = _colsum(dy2, M, C, row_scale=s1, rps=H * W, out=dst)
+        dbproj, s_bp = _sink(pbproj)
+        dwproj = _wgrad(o, dy2, C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw, out=dst, dbias=dbproj)
         # attention core
         dqkv = _e((Mw, 3 * C), BF16, dev)
         part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads),), F32, dev)
@@ -416,9 +417,8 @@ class _AttnHalf(torch.autograd.Function):
         # qkv linear: scatter the token gradients back to pixel rows (pad tokens dropped)
         du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
         dst, s_wq = _sink(pwqkv)
-        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw, out=dst)
-        dst, s_bq = _sink(pbqkv)
-        dbqkv = _colsum(dqkv, Mw, 3 * C, out=dst)
+        dbqkv, s_bq = _sink(pbqkv)
+        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw, out=dst, dbias=dbqkv)
         dx, dg1, db1 = _layernorm_bwd(du, x2, mean, rstd, g1, dy2, pg1, pb1)
         return (dx.view(B, H, W, C), dg1, db1, None if s_t else dtable, None if s_wq else dwqkv, None if s_bq else dbqkv,
                 None if s_wp else dwproj, None if s_bp else dbproj, None, None)
@@ -454,14 +454,12 @@ class _MlpHalf(torch.autograd.Function):
         pg2, pb2, pw1, pbias1, pw2, pbias2 = ctx.params
         dz = _linear(dy2, w2_t, M, Hd, C, res_scale=s2, gelu_of=z, rps=H * W)        # (dy W2) * s2 * gelu'(z)
         dst, s_w2 = _sink(pw2)
-        dw2 = _wgrad(h, dy2, C, Hd, 1, 1, None, g_scale=s2, g_rps=H * W, M=M, out=dst)
-        dst, s_b2 = _sink(pbias2)
-        db2 = _colsum(dy2, M, C, row_scale=s2, rps=H * W, out=dst)
+        db2, s_b2 = _sink(pbias2)
+        dw2 = _wgrad(h, dy2, C, Hd, 1, 1, None, g_scale=s2, g_rps=H * W, M=M, out=dst, dbias=db2)
         dv = _linear(dz, w1_t, M, C, Hd)
         dst, s_w1 = _sink(pw1)
-        dw1 = _wgrad(v, dz, Hd, C, 1, 1, None, M=M, out=dst)
-        dst, s_b1 = _sink(pbias1)
-        db1 = _colsum(dz, M, Hd, out=dst)
+        db1, s_b1 = _sink(pbias1)
+        dw1 = _wgrad(v, dz, Hd, C, 1, 1, None, M=M, out=dst, dbias=db1)
         dx, dg2, dbt2 = _layernorm_bwd(dv, x2, mean, rstd, g2, dy2, pg2, pb2)
         return (dx.view(B, H, W, C), dg2, dbt2, None if s_w1 else dw1, None if s_b1 else db1, None if s_w2 else dw2,
                 None if s_b2 else db2, None)

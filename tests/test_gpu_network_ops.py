@@ -232,10 +232,12 @@ def test_linear_rowmaps_gelu_residual(N):
     assert err(C(g), (x[:64] @ w.T) * zr.grad) < 8e-3
     # linear wgrad with maps and scale, bias column sums
     gout = rnd(B * H * W, Cc, seed=7)
-    dw = N._wgrad(tok.to(DEV, BF), gout.to(DEV, BF), Cc, Nn, 1, 1, None, g_map=amap, g_scale=s.to(DEV), g_rps=H * W, M=amap.numel())
+    dbias = torch.empty(Cc, device=DEV)
+    dw = N._wgrad(tok.to(DEV, BF), gout.to(DEV, BF), Cc, Nn, 1, 1, None, g_map=amap, g_scale=s.to(DEV), g_rps=H * W, M=amap.numel(), dbias=dbias)
     gg = torch.zeros(amap.numel(), Cc)
     gg[valid] = gout[am[valid]] * s[(am[valid] // (H * W))][:, None]
     assert err(C(dw), gg.T @ tok) < 1e-2          # scaled rows are re-rounded to bf16 inside the kernel
+    assert err(C(dbias), gg.sum(0)) < 1e-2        # bias gradient from the same staged tile
     db = N._colsum(gout.to(DEV, BF), B * H * W, Cc, row_scale=s.to(DEV), rps=H * W)
     assert err(C(db), (gout * s.repeat_interleave(H * W)[:, None]).sum(0)) < 2e-3
 

@@ -86,7 +86,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly instead of replaying the captured hipGraph of the step")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one captured hipGraph (single stream) instead of eager launches with concurrent branch streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -111,7 +112,7 @@ def main():
     cfg = get_config("hrformer_small")
     cfg.train.batch_size = PER_GPU_BATCH
     model = build_model(cfg).to(dev)
-    use_graph = not args.no_graph and os.environ.get("POSE_NO_GRAPH", "0") != "1"
+    use_graph = args.graph or os.environ.get("POSE_GRAPH", "0") == "1"
     trainer = engine.Trainer(model, cfg, iters_per_epoch=1000, use_graph=use_graph, graph_warmup=2)
     batch = synthetic_batch(PER_GPU_BATCH, INPUT_SIZE, HEATMAP_SIZE, K, 2.0, dev, seed=1234 + rank)
     args.warmup = max(args.warmup, 4) if use_graph else args.warmup      # 2 eager steps + capture + 1 replay before timing
@@ -157,7 +158,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "HRFormer-small + fusion head, 256x192 -> 64x48, K=17, train step fwd+bwd+AdamW, DropPath 0.1, BN train",
                        "global_batch": PER_GPU_BATCH * world, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay" if trainer._graph is not None else "eager"},
+                       "launch": "hipGraph replay (single stream)" if trainer._graph is not None else
+                       ("eager, branches on concurrent HIP streams" if dispatch.streams_enabled() else "eager, single stream")},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
             "impl": dict(impl_table, loss="hip", target="hip", decode="hip", adamw="hip"),
             "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP; 'aten' entries are PyTorch-ROCm stop-gaps",

@@ -6,6 +6,9 @@ kernels, NHWC bf16 tensors, bf16 weight cache refreshed on entry) when every lay
 backbone called from PoseEstimator shares its weight cache.  `backend_name(model)` reports the choice.
 """
 import contextlib
+import os
+
+import torch
 
 from . import nnops, nnops_aten
 
@@ -85,3 +88,62 @@ def from_public(x):
             return nnops.to_features(x, cpad=-(-C // 8) * 8)
         return nnops_aten.to_features(x)
     return x.permute(0, 2, 3, 1).contiguous() if ops() is nnops else x
+
+
+# ---------------------------------------------------------------------------------------------- branch concurrency
+# The 2-4 resolution branches of an HRNet/HRFormer module are independent between exchange units, and only branch 0
+# (64x48 at B=64) has enough workgroups to fill 256 CUs; the others are latency-bound launches of < 256 workgroups.
+# `parallel` runs callable 0 on the current stream and the others on per-device side streams (fork: side.wait(current);
+# join: current.wait(side)), so the small branches hide under the big one.  Backward follows automatically: autograd
+# replays each node on the stream its forward ran on and joins at the end.  Under hipGraph capture the fork/join
+# becomes parallel graph branches.  POSE_STREAMS=0 disables it.
+_SIDE = {}
+_STREAMS_OFF = [False]     # set by engine.Trainer(use_graph=True): multi-stream capture crashes hipStreamEndCapture on ROCm 7.2
+
+
+def set_streams(enabled: bool):
+    _STREAMS_OFF[0] = not enabled
+
+
+def streams_enabled() -> bool:
+    return (not _STREAMS_OFF[0]) and os.environ.get("POSE_STREAMS", "1") != "0" and torch.cuda.is_available()
+
+
+def _side_stream(dev, i):
+    key = (dev.index if dev.index is not None else torch.cuda.current_device(), i)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
+
+def _tensors(obj):
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, (list, tuple)):
+        for o in obj:
+            yield from _tensors(o)
+
+
+def parallel(fns, inputs=None):
+    """Run fns[0] on the current stream and fns[1:] concurrently on side streams; returns their results in order.
+    `inputs[i]` (tensor / list of tensors) are the tensors fns[i] reads that were produced on other streams."""
+    n = len(fns)
+    if n == 1 or not streams_enabled() or ops() is not nnops:
+        return [f() for f in fns]
+    cur = torch.cuda.current_stream()
+    outs = [None] * n
+    side = [None] + [_side_stream(cur.device, i) for i in range(1, n)]
+    for i in range(1, n):                     # fork first: side streams depend only on work enqueued before this point
+        side[i].wait_stream(cur)
+        if inputs is not None:
+            for t in _tensors(inputs[i]):
+                t.record_stream(side[i])
+    outs[0] = fns[0]()                        # then run in index order, so autograd nodes are created exactly as in the
+    for i in range(1, n):                     # sequential schedule (same backward order, same bf16 accumulation order)
+        with torch.cuda.stream(side[i]):
+            outs[i] = fns[i]()
+    for i in range(1, n):
+        cur.wait_stream(side[i])
+        for t in _tensors(outs[i]):
+            t.record_stream(cur)
+    return outs

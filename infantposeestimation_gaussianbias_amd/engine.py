@@ -296,6 +296,9 @@ class Trainer:
         # capture therefore run on ONE dedicated side stream, otherwise backward would sync with the (non-capturing)
         # default stream in the middle of the capture
         self._stream = torch.cuda.Stream() if (use_graph and torch.cuda.is_available()) else None
+        if use_graph:
+            from . import dispatch
+            dispatch.set_streams(False)     # branch side-streams and graph capture are mutually exclusive (see dispatch.py)
         self._eager_steps = 0
         self._graph = None
         self._static = None
@@ -344,6 +347,8 @@ class Trainer:
 
     def step(self, batch):
         if not self.use_graph:
+            from . import dispatch
+            dispatch.set_streams(True)
             return self._eager_step(batch)
         if self._graph is None:
             if self._eager_steps < self.graph_warmup:

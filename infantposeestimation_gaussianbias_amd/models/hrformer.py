@@ -60,14 +60,21 @@ class HRFormerModule(nn.Module):
 
     def forward(self, xs, scales=None):
         """scales: (n_draws, B) DropPath multipliers for this module (two per block, branch-major), or None."""
-        ys, d = [], 0
+        def make(b, blocks, d0):
+            def run():
+                t, d = xs[b], d0
+                for blk in blocks:
+                    s1, s2 = (scales[d], scales[d + 1]) if scales is not None else (None, None)
+                    d += 2
+                    t = nnops.window_block(t, blk, blk.heads, s1, s2)
+                return t
+            return run
+
+        fns, d = [], 0
         for b, blocks in enumerate(self.branches):
-            t = xs[b]
-            for blk in blocks:
-                s1, s2 = (scales[d], scales[d + 1]) if scales is not None else (None, None)
-                d += 2
-                t = nnops.window_block(t, blk, blk.heads, s1, s2)
-            ys.append(t)
+            fns.append(make(b, blocks, d))
+            d += 2 * len(blocks)
+        ys = nnops.parallel(fns, [[xs[b]] + ([scales] if scales is not None else []) for b in range(len(fns))])
         if len(ys) == 1:
             return ys
         return nnops.exchange(ys, self.fuse_layers, self.training)

@@ -19,12 +19,15 @@ class HighResolutionModule(nn.Module):
             self.fuse_layers = make_fuse_layers(channels)
 
     def forward(self, xs):
-        ys = []
-        for b, blocks in enumerate(self.branches):
-            t = xs[b]
-            for blk in blocks:
-                t = blk(t)
-            ys.append(t)
+        def make(b, blocks):
+            def run():
+                t = xs[b]
+                for blk in blocks:
+                    t = blk(t)
+                return t
+            return run
+
+        ys = nnops.parallel([make(b, blocks) for b, blocks in enumerate(self.branches)], [[x] for x in xs])
         return ys if len(ys) == 1 else nnops.exchange(ys, self.fuse_layers, self.training)
 
 

@@ -520,24 +520,29 @@ def fuse_sum(xs, relu=True):
 
 def exchange(xs, fuse, training, n_out=None):
     """Exchange unit (hrformer.py:462-491 == hrnet.py:198-227): out_i = relu(sum_j route_{j->i}(x_j))."""
+    from . import dispatch
     n = len(xs)
-    outs = []
-    for i in range(n if n_out is None else n_out):
-        terms = []
-        for j in range(n):
-            if j == i:
-                terms.append(xs[j])
-            elif j > i:
-                conv, bn = fuse[str(i)][str(j)]
-                terms.append(conv_bn_act(xs[j], conv, bn, False, None, training))      # up-sampled inside fuse_sum
-            else:
-                t = xs[j]
-                chain = fuse[str(i)][str(j)]
-                for s, (conv, bn) in enumerate(chain):
-                    t = conv_bn_act(t, conv, bn, s != len(chain) - 1, None, training)
-                terms.append(t)
-        outs.append(fuse_sum(terms, True))
-    return outs
+
+    def make(i):
+        def run():
+            terms = []
+            for j in range(n):
+                if j == i:
+                    terms.append(xs[j])
+                elif j > i:
+                    conv, bn = fuse[str(i)][str(j)]
+                    terms.append(conv_bn_act(xs[j], conv, bn, False, None, training))      # up-sampled inside fuse_sum
+                else:
+                    t = xs[j]
+                    chain = fuse[str(i)][str(j)]
+                    for s, (conv, bn) in enumerate(chain):
+                        t = conv_bn_act(t, conv, bn, s != len(chain) - 1, None, training)
+                    terms.append(t)
+            return fuse_sum(terms, True)
+        return run
+
+    n_o = n if n_out is None else n_out
+    return dispatch.parallel([make(i) for i in range(n_o)], [list(xs)] * n_o)
 
 
 def drop_scales(n_draws, batch, drop_prob, device):

@@ -348,3 +348,31 @@ def test_graph_replay_matches_eager_steps():
         traj[mode] = [float(tr.step(batches[i % 3])["loss"].detach()) for i in range(7)]
         assert (tr._graph is not None) == mode
     assert np.allclose(traj[False], traj[True], rtol=2e-3), traj
+
+
+def test_branch_streams_are_bitwise_identical_to_single_stream():
+    """Running the resolution branches on concurrent HIP streams must not change a single bit of the training
+    trajectory (same kernels, same order of every reduction): a difference here would mean a cross-stream race."""
+    from infantposeestimation_gaussianbias_amd import dispatch, engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    batches = [synthetic_batch(8, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=50 + i) for i in range(2)]
+    runs = []
+    for streams in ("1", "0", "1"):
+        os.environ["POSE_STREAMS"] = streams
+        try:
+            torch.manual_seed(0)
+            model = build_model(cfg).to(DEV)
+            tr = engine.Trainer(model, cfg, iters_per_epoch=2)
+            losses = [tr.step(batches[i % 2])["loss"].detach().clone() for i in range(6)]      # DropPath on (seeded)
+            assert dispatch.streams_enabled() == (streams == "1")
+            torch.cuda.synchronize()
+            runs.append((torch.stack(losses).cpu(), tr.opt.flat.detach().cpu().clone()))
+        finally:
+            os.environ.pop("POSE_STREAMS", None)
+    for losses, flat in runs[1:]:
+        assert torch.equal(losses, runs[0][0]), (losses, runs[0][0])
+        assert torch.equal(flat, runs[0][1])

@@ -73,6 +73,15 @@ def call(name, *args):
         raise PoseKernelError(f"{name} failed (code {rc}): {lib.pk_last_error_string().decode()}")
 
 
+_raw_stream = None
+
+
 def stream_ptr():
+    """Raw hipStream_t of torch's current stream on the current device (fast path: one C call, no Stream object)."""
+    global _raw_stream
     import torch
+    if _raw_stream is None:
+        _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", False)
+    if _raw_stream:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream

@@ -123,7 +123,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _dp_worker(rank, world, port, q):
+def _dp_worker(rank, world, port, q, overlap):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -137,7 +137,7 @@ def _dp_worker(rank, world, port, q):
             for p in model.parameters():
                 p.add_(1.0)                              # diverge on purpose: broadcast must repair it
     opt = engine.FlatAdamW(model)
-    comm = engine.GradientExchange(opt, bucket_mb=0.0001)  # ~26 elements per bucket -> several buckets
+    comm = engine.GradientExchange(opt, bucket_mb=0.0001, overlap=overlap)  # ~26 elements per bucket -> several buckets
     comm.broadcast_initial_state()
     g = torch.Generator().manual_seed(123)
     data = torch.randn(8, 6, generator=g)
@@ -154,11 +154,12 @@ def _dp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gradient_exchange_world2_matches_single_process():
+@pytest.mark.parametrize("overlap", [False, True])
+def test_gradient_exchange_world2_matches_single_process(overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q, overlap)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=120) for _ in procs], key=lambda t: t[0])

@@ -45,12 +45,31 @@ struct IgemmArgs {
     int rows_per_sample;      // rows of one sample (for res_scale): Ho*Wo or tokens per image
     int act;                  // 0 none, 1 GELU(erf), 2 softplus
     int out_mode;             // 0 bf16 row-major, 1 fp32 row-major, 2 fp32 NCHW planes [B][N][Ho*Wo]
+    int vec8;                 // set by igemm_launch: row-major pointers 16-byte aligned and ldo % 8 == 0 -> 16-byte epilogue I/O
 };
 
-__device__ __forceinline__ float gelu_erf(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+// erf via Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at fp32 rounding level and 4 orders of magnitude below the
+// bf16 rounding of every tensor these activations are stored to): one v_rcp, one v_exp, five FMAs.  libm's erff inlines
+// to ~60 instructions with a divergent branch, and the epilogue evaluates it for every element of the MLP hidden layer.
+// `e` = exp(-x*x) is passed in because GELU's derivative needs the same exponential.
+__device__ __forceinline__ float erf_as(float x, float e) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(__fmaf_rn(0.3275911f, ax, 1.f));
+    float q = __fmaf_rn(1.061405429f, t, -1.453152027f);
+    q = __fmaf_rn(q, t, 1.421413741f);
+    q = __fmaf_rn(q, t, -0.284496736f);
+    q = __fmaf_rn(q, t, 0.254829592f);
+    const float r = 1.f - q * t * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float e = __expf(-0.5f * v * v);
+    return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f, e));
+}
 __device__ __forceinline__ float softplus_(float v) { return v > 20.f ? v : log1pf(__expf(v)); }
 __device__ __forceinline__ float gelu_grad(float z) {
-    return 0.5f * (1.f + erff(z * 0.70710678118654752440f)) + z * 0.39894228040143267794f * __expf(-0.5f * z * z);
+    const float e = __expf(-0.5f * z * z);
+    return 0.5f * (1.f + erf_as(z * 0.70710678118654752440f, e)) + z * 0.39894228040143267794f * e;
 }
 
 // ================================================================================================ main kernel (v2)
@@ -67,85 +86,100 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 template <int BK>
 __device__ __forceinline__ int swz(int row) { return BK == 64 ? ((row >> 1) & 7) : (((row >> 3) & 1) << 1); }
 
-// Epilogue of ONE 16x16 accumulator tile: this lane owns output row `orow` (pixel / token) and columns n..n+3.
-// Kept as a force-inlined function with only static register indexing so the accumulator array stays in registers
-// (an epilogue written inline with `continue`s and tail loops made hipcc index acc[][] dynamically -> scratch).
-__device__ __forceinline__ void igemm_epilogue_tile(const IgemmArgs& p, f32x4 c, int orow, int n, float rs, int hw_out) {
-    if (n >= p.N) return;
-    const bool full = n + 3 < p.N;
+// Epilogue of ONE output row segment: this lane owns output row `orow` (pixel / token) and the 8 consecutive columns
+// n..n+7, handed over as two float4 read back from the LDS staging tile.  The accumulators are staged through LDS so
+// that (a) every global access of the epilogue is a 16-byte access and a wave covers whole 128/256-byte row segments
+// (the MFMA C layout would give 8-byte pieces of 16 different rows per instruction), and (b) the epilogue is ONE rolled
+// loop: unrolled per accumulator tile it was ~2000 instructions x 16 tiles (erff inlined 64 times, 250 KB of code for
+// one kernel), which made the K=32 GEMMs instruction-fetch bound.  Only static indexing of v[] (no scratch).
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
+__device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+
+__device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo, f32x4 hi, int orow, int n, float rs, int hw_out) {
+    float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const int nv = p.N - n;                               // valid columns of this segment (>= 1)
+    const bool vec = p.vec8 && nv >= 8;
     const size_t base = (size_t)orow * p.ldo + n;
-    float v0 = c[0], v1 = c[1], v2 = c[2], v3 = c[3];
     if (p.bias) {
-        v0 += p.bias[n];
-        if (n + 1 < p.N) v1 += p.bias[n + 1];
-        if (n + 2 < p.N) v2 += p.bias[n + 2];
-        if (n + 3 < p.N) v3 += p.bias[n + 3];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nv) v[j] += p.bias[n + j];
     }
     if (p.preact) {
-        if (full) {
-            uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
-            *reinterpret_cast<uint2*>(p.preact + base) = pk;
+        if (vec) {
+            *reinterpret_cast<u32x4*>(p.preact + base) =
+                (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         } else {
-            p.preact[base] = f32_to_bf16(v0);
-            if (n + 1 < p.N) p.preact[base + 1] = f32_to_bf16(v1);
-            if (n + 2 < p.N) p.preact[base + 2] = f32_to_bf16(v2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nv) p.preact[base + j] = f32_to_bf16(v[j]);
         }
     }
     if (p.gelu_of) {
-        if (full) {
-            const uint2 zz = *reinterpret_cast<const uint2*>(p.gelu_of + base);
-            v0 *= gelu_grad(bf16_to_f32((uint16_t)(zz.x & 0xffff))); v1 *= gelu_grad(bf16_to_f32((uint16_t)(zz.x >> 16)));
-            v2 *= gelu_grad(bf16_to_f32((uint16_t)(zz.y & 0xffff))); v3 *= gelu_grad(bf16_to_f32((uint16_t)(zz.y >> 16)));
+        if (vec) {
+            const u32x4 zz = *reinterpret_cast<const u32x4*>(p.gelu_of + base);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] *= gelu_grad(bf16_lo(zz[j]));
+                v[2 * j + 1] *= gelu_grad(bf16_hi(zz[j]));
+            }
         } else {
-            v0 *= gelu_grad(bf16_to_f32(p.gelu_of[base]));
-            if (n + 1 < p.N) v1 *= gelu_grad(bf16_to_f32(p.gelu_of[base + 1]));
-            if (n + 2 < p.N) v2 *= gelu_grad(bf16_to_f32(p.gelu_of[base + 2]));
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nv) v[j] *= gelu_grad(bf16_to_f32(p.gelu_of[base + j]));
         }
     }
-    if (p.act == 1) { v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3); }
-    else if (p.act == 2) { v0 = softplus_(v0); v1 = softplus_(v1); v2 = softplus_(v2); v3 = softplus_(v3); }
-    v0 *= rs; v1 *= rs; v2 *= rs; v3 *= rs;
+    if (p.act == 1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+    } else if (p.act == 2) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = softplus_(v[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] *= rs;
     if (p.out_mode == 2) {
         const int bb = orow / hw_out, pix = orow - bb * hw_out;
         float* o = reinterpret_cast<float*>(p.out) + ((size_t)bb * p.N + n) * hw_out + pix;
-        o[0] = v0;
-        if (n + 1 < p.N) o[(size_t)hw_out] = v1;
-        if (n + 2 < p.N) o[(size_t)2 * hw_out] = v2;
-        if (n + 3 < p.N) o[(size_t)3 * hw_out] = v3;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (j < nv) o[(size_t)j * hw_out] = v[j];
         return;
     }
     if (p.res) {
-        if (full) {
-            const uint2 rv = *reinterpret_cast<const uint2*>(p.res + base);
-            v0 += bf16_to_f32((uint16_t)(rv.x & 0xffff)); v1 += bf16_to_f32((uint16_t)(rv.x >> 16));
-            v2 += bf16_to_f32((uint16_t)(rv.y & 0xffff)); v3 += bf16_to_f32((uint16_t)(rv.y >> 16));
+        if (vec) {
+            const u32x4 rv = *reinterpret_cast<const u32x4*>(p.res + base);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[2 * j] += bf16_lo(rv[j]);
+                v[2 * j + 1] += bf16_hi(rv[j]);
+            }
         } else {
-            v0 += bf16_to_f32(p.res[base]);
-            if (n + 1 < p.N) v1 += bf16_to_f32(p.res[base + 1]);
-            if (n + 2 < p.N) v2 += bf16_to_f32(p.res[base + 2]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nv) v[j] += bf16_to_f32(p.res[base + j]);
         }
     }
     if (p.out_mode == 0) {
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + base;
-        if (full) {
-            uint2 pk;
-            pk.x = (uint32_t)f32_to_bf16(v0) | ((uint32_t)f32_to_bf16(v1) << 16);
-            pk.y = (uint32_t)f32_to_bf16(v2) | ((uint32_t)f32_to_bf16(v3) << 16);
-            *reinterpret_cast<uint2*>(o) = pk;
+        if (vec) {
+            *reinterpret_cast<u32x4*>(o) =
+                (u32x4){pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3]), pack_bf16x2(v[4], v[5]), pack_bf16x2(v[6], v[7])};
         } else {
-            o[0] = f32_to_bf16(v0);
-            if (n + 1 < p.N) o[1] = f32_to_bf16(v1);
-            if (n + 2 < p.N) o[2] = f32_to_bf16(v2);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nv) o[j] = f32_to_bf16(v[j]);
         }
     } else {
         float* o = reinterpret_cast<float*>(p.out) + base;
-        if (full) *reinterpret_cast<float4*>(o) = make_float4(v0, v1, v2, v3);
-        else {
-            o[0] = v0;
-            if (n + 1 < p.N) o[1] = v1;
-            if (n + 2 < p.N) o[2] = v2;
+        if (vec) {
+            *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                if (j < nv) o[j] = v[j];
         }
     }
 }
@@ -157,7 +191,10 @@ __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
     constexpr int A_PT = BM * CH / 256;              // A chunks per thread (2 or 4)
     constexpr int B_PT = (BN * CH + 255) / 256;      // B chunks per thread (1..4)
     constexpr int KS = BK / 32;                      // MFMA k-steps per staged tile
-    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * BM * BK + 2 * BN * BK];
+    constexpr int TM = BM / WM, TN = BN / WN;        // tile of one wave
+    constexpr int EP = TN + 4;                       // fp32 pitch of the epilogue staging tile (conflict-free b128 rows)
+    constexpr int MAIN_HALFS = 2 * BM * BK + 2 * BN * BK, EPI_HALFS = 4 * TM * EP * 2;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[MAIN_HALFS > EPI_HALFS ? MAIN_HALFS : EPI_HALFS];
     uint16_t* sA = smem;                             // [2][BM*BK]
     uint16_t* sB = smem + 2 * BM * BK;               // [2][BN*BK]
     float* sStat = reinterpret_cast<float*>(smem);   // [WM][BN][2], reused after the main loop
@@ -336,24 +373,38 @@ __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
         }
     }
 
-    // ---- epilogue (per-tile, static register indexing only)
-    const int hw_out = p.Ho * p.Wo;
+    // ---- epilogue: accumulators -> wave-private fp32 LDS tile -> rolled loop over 8-column row segments
+    if (p.stats) __syncthreads();                    // sStat (aliases the staging tile) has been consumed
+    float* stage = reinterpret_cast<float*>(smem) + wave * TM * EP;
 #pragma unroll
-    for (int b = 0; b < MI; ++b) {
-        const int m = m0 + wm * (BM / WM) + b * 16 + (lane & 15);
+    for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+            *reinterpret_cast<f32x4*>(&stage[(b * 16 + (lane & 15)) * EP + a * 16 + (lane >> 4) * 4]) = acc[a][b];
+    __syncthreads();
+    constexpr int LPR = TN / 8, RPP = 64 / LPR;      // lanes per row, rows per pass
+    const int hw_out = p.Ho * p.Wo;
+    const int lr = lane / LPR, lc = (lane % LPR) * 8;
+    const int n = n0 + wn * TN + lc;
+    if (n >= p.N) return;
+#pragma unroll 2
+    for (int ps = 0; ps < TM / RPP; ++ps) {
+        const int ml = ps * RPP + lr;
+        const int m = m0 + wm * TM + ml;
         int orow = (m < p.M) ? m : -1;
         if (orow >= 0 && p.o_rowmap) orow = p.o_rowmap[m];
-        float rs = 1.f;
-        if (orow >= 0 && p.res_scale) rs = p.res_scale[orow / p.rows_per_sample];
-#pragma unroll
-        for (int a = 0; a < NI; ++a) {
-            const int n = n0 + wn * (BN / WN) + a * 16 + (lane >> 4) * 4;
-            if (orow >= 0) igemm_epilogue_tile(p, acc[a][b], orow, n, rs, hw_out);
-        }
+        if (orow < 0) continue;
+        const float rs = p.res_scale ? p.res_scale[orow / p.rows_per_sample] : 1.f;
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc]);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc + 4]);
+        igemm_epilogue_row8(p, lo, hi, orow, n, rs, hw_out);
     }
 }
 
-static int igemm_launch(const IgemmArgs& a, hipStream_t st, const char* who) {
+static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) {
+    IgemmArgs a = a_in;
+    a.vec8 = (a.ldo % 8) == 0 &&
+             ((((uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.preact | (uintptr_t)a.gelu_of) & 15) == 0);
     const dim3 block(256);
     const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
     const bool k64 = (a.Cin % 64) == 0;              // deeper K-chunks when the channel count allows full 64-wide tiles

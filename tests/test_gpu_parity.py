@@ -376,3 +376,60 @@ def test_branch_streams_are_bitwise_identical_to_single_stream():
     for losses, flat in runs[1:]:
         assert torch.equal(losses, runs[0][0]), (losses, runs[0][0])
         assert torch.equal(flat, runs[0][1])
+
+
+def _dp_gpu_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from infantposeestimation_gaussianbias_amd import engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    shard = synthetic_batch(2, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, "cuda", seed=50 + rank)
+    torch.manual_seed(rank)                                  # ranks start from DIFFERENT weights: broadcast repairs it
+    model = build_model(cfg).to("cuda")
+    model.backbone.drop_path_rate = 0.0
+    tr = engine.Trainer(model, cfg, iters_per_epoch=2)
+    init = tr.opt.flat.clone()
+    # local gradient of this shard from the broadcast weights, no exchange
+    world_saved, tr.comm.world = tr.comm.world, 1
+    tr._fwd_bwd(shard)
+    local = tr.opt.grad.clone()
+    tr.comm.world = world_saved
+    # (the probe pass also advanced the BN running statistics; training-mode gradients do not depend on them)
+    out = tr.step(shard)
+    torch.cuda.synchronize()
+    # numpy arrays are pickled by value (tensors would travel as file descriptors the exiting worker takes with it)
+    q.put((rank, init.cpu().numpy(), local.cpu().numpy(), tr.opt.grad.cpu().numpy(), tr.opt.flat.cpu().numpy(), float(out["loss"])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_trainer_data_parallel_two_ranks_one_gpu():
+    """World-size-2 Trainer step (gloo carrying the HIP-produced flat gradient): summed gradient == sum of the ranks'
+    local gradients, and both ranks hold identical weights before and after the step (reference: DDP in train.py)."""
+    import socket
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (_, i0, l0, g0, f0, loss0), (_, i1, l1, g1, f1, loss1) = res
+    assert np.array_equal(i0, i1)                                    # broadcast of rank 0's initial state
+    assert np.array_equal(g0, g1) and np.array_equal(f0, f1)         # same summed gradient, same updated weights
+    assert np.array_equal(g0, l0 + l1)                               # the exchange is an exact two-term sum
+    assert not np.array_equal(f0, i0) and np.isfinite(loss0) and np.isfinite(loss1)

@@ -285,9 +285,12 @@ class Trainer:
     per-iteration schedule advances normally.  Batches are copied into static input buffers."""
 
     def __init__(self, model, cfg, iters_per_epoch: int, bucket_mb: float = 16.0, use_graph: bool = False, graph_warmup: int = 3,
-                 overlap_comm: bool = False):
+                 overlap_comm: bool = False, graph_streams: bool = False):
         self.model, self.cfg = model, cfg
         self.overlap_comm = overlap_comm
+        # concurrent branch streams: on for eager steps (unless hook-driven comm overlap needs single-stream autograd);
+        # inside a captured graph only on request (fork/join capture across streams, see scripts/gpu_graph_streams.py)
+        self._want_streams = graph_streams if use_graph else (not overlap_comm)
         t = cfg.train
         if t.optimizer != "AdamW":
             raise ValueError(f"Unknown optimizer: {t.optimizer}")   # the fused kernel implements the reference default only
@@ -301,9 +304,6 @@ class Trainer:
         # capture therefore run on ONE dedicated side stream, otherwise backward would sync with the (non-capturing)
         # default stream in the middle of the capture
         self._stream = torch.cuda.Stream() if (use_graph and torch.cuda.is_available()) else None
-        if use_graph:
-            from . import dispatch
-            dispatch.set_streams(False)     # branch side-streams and graph capture are mutually exclusive (see dispatch.py)
         self._eager_steps = 0
         self._graph = None
         self._static = None
@@ -352,9 +352,9 @@ class Trainer:
         return self._static_out
 
     def step(self, batch):
+        from . import dispatch
+        dispatch.set_streams(self._want_streams)
         if not self.use_graph:
-            from . import dispatch
-            dispatch.set_streams(not self.overlap_comm)     # hook-driven comm overlap needs single-stream autograd
             return self._eager_step(batch)
         if self._graph is None:
             if self._eager_steps < self.graph_warmup:

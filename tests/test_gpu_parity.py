@@ -400,6 +400,7 @@ def _dp_gpu_worker(rank, world, port, q):
     # local gradient of this shard from the broadcast weights, no exchange
     world_saved, tr.comm.world = tr.comm.world, 1
     tr._fwd_bwd(shard)
+    tr.opt.install_grad_views()                              # first backward: adopt autograd's gradients into the flat buffer
     local = tr.opt.grad.clone()
     tr.comm.world = world_saved
     # (the probe pass also advanced the BN running statistics; training-mode gradients do not depend on them)

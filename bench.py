@@ -86,8 +86,9 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as one captured hipGraph (single stream) instead of eager launches with concurrent branch streams")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel from the host each step instead of replaying the captured hipGraph")
+    ap.add_argument("--single-stream", action="store_true", help="do not run the resolution branches on concurrent HIP streams")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -112,8 +113,13 @@ def main():
     cfg = get_config("hrformer_small")
     cfg.train.batch_size = PER_GPU_BATCH
     model = build_model(cfg).to(dev)
-    use_graph = args.graph or os.environ.get("POSE_GRAPH", "0") == "1"
-    trainer = engine.Trainer(model, cfg, iters_per_epoch=1000, use_graph=use_graph, graph_warmup=2)
+    # default: the whole step (zero_grad + fwd + bwd + AdamW; with N>1 the RCCL all-reduce and AdamW stay outside) is one
+    # hipGraph whose branches fork/join across HIP streams
+    use_graph = not (args.eager or os.environ.get("POSE_GRAPH", "1") == "0")
+    streams = not (args.single_stream or os.environ.get("POSE_STREAMS", "1") == "0")
+    if not streams:
+        os.environ["POSE_STREAMS"] = "0"
+    trainer = engine.Trainer(model, cfg, iters_per_epoch=1000, use_graph=use_graph, graph_warmup=2, graph_streams=streams)
     batch = synthetic_batch(PER_GPU_BATCH, INPUT_SIZE, HEATMAP_SIZE, K, 2.0, dev, seed=1234 + rank)
     args.warmup = max(args.warmup, 4) if use_graph else args.warmup      # 2 eager steps + capture + 1 replay before timing
 
@@ -158,8 +164,8 @@ def main():
             "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "HRFormer-small + fusion head, 256x192 -> 64x48, K=17, train step fwd+bwd+AdamW, DropPath 0.1, BN train",
                        "global_batch": PER_GPU_BATCH * world, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}",
-                       "launch": "hipGraph replay (single stream)" if trainer._graph is not None else
-                       ("eager, branches on concurrent HIP streams" if dispatch.streams_enabled() else "eager, single stream")},
+                       "launch": ("hipGraph replay" if trainer._graph is not None else "eager launches") +
+                       (", branches on concurrent HIP streams" if dispatch.streams_enabled() else ", single stream")},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
             "impl": dict(impl_table, loss="hip", target="hip", decode="hip", adamw="hip"),
             "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP; 'aten' entries are PyTorch-ROCm stop-gaps",

@@ -94,15 +94,28 @@ def from_public(x):
 # The 2-4 resolution branches of an HRNet/HRFormer module are independent between exchange units, and only branch 0
 # (64x48 at B=64) has enough workgroups to fill 256 CUs; the others are latency-bound launches of < 256 workgroups.
 # `parallel` runs callable 0 on the current stream and the others on per-device side streams (fork: side.wait(current);
-# join: current.wait(side)), so the small branches hide under the big one.  Backward follows automatically: autograd
-# replays each node on the stream its forward ran on and joins at the end.  Under hipGraph capture the fork/join
-# becomes parallel graph branches.  POSE_STREAMS=0 disables it.
+# join: current.wait(side)), so the small branches hide under the big one.  Two implementations:
+#   * eager (default): the callables run under `torch.cuda.stream(side)`; autograd replays each node on the stream its
+#     forward ran on and inserts its own cross-stream events in backward;
+#   * region mode (`set_region_mode(True)`, used for hipGraph capture): the whole fork/join is ONE autograd node.  Its
+#     forward builds a private autograd graph per callable on that callable's stream; its backward forks again, runs
+#     each private graph with a nested backward on its own stream and joins.  From the outer engine's point of view
+#     everything happens on one stream, so the captured graph has the same star-shaped fork/join in forward and
+#     backward.  (Capturing the eager variant crashes hipStreamEndCapture on ROCm 7.2 - scripts/gpu_graph_streams.py:
+#     the engine's direct side-stream <-> side-stream event edges in backward are the difference.)
+# POSE_STREAMS=0 disables both.
 _SIDE = {}
-_STREAMS_OFF = [False]     # set by engine.Trainer(use_graph=True): multi-stream capture crashes hipStreamEndCapture on ROCm 7.2
+_STREAMS_OFF = [False]
+_REGION = [False]
+_EVENTS = []               # events used for fork/join stay alive: a captured graph may refer to them until the capture ends
 
 
 def set_streams(enabled: bool):
     _STREAMS_OFF[0] = not enabled
+
+
+def set_region_mode(enabled: bool):
+    _REGION[0] = bool(enabled)
 
 
 def streams_enabled() -> bool:
@@ -116,6 +129,13 @@ def _side_stream(dev, i):
     return _SIDE[key]
 
 
+def join_side_streams(cur=None):
+    """Make `cur` wait for everything enqueued so far on every side stream."""
+    cur = cur or torch.cuda.current_stream()
+    for s in _SIDE.values():
+        cur.wait_stream(s)
+
+
 def _tensors(obj):
     if torch.is_tensor(obj):
         yield obj
@@ -124,24 +144,101 @@ def _tensors(obj):
             yield from _tensors(o)
 
 
-def parallel(fns, inputs=None):
-    """Run fns[0] on the current stream and fns[1:] concurrently on side streams; returns their results in order.
-    `inputs[i]` (tensor / list of tensors) are the tensors fns[i] reads that were produced on other streams."""
+def _order(src, dst):
+    """dst waits for everything enqueued on src so far."""
+    ev = torch.cuda.Event()
+    ev.record(src)
+    dst.wait_event(ev)
+    if torch.cuda.is_current_stream_capturing():
+        _EVENTS.append(ev)
+    elif _EVENTS:
+        _EVENTS.clear()
+
+
+class _Region(torch.autograd.Function):
+    """fork -> fns[i](inputs_i) on stream i -> join, as one autograd node (see the section comment)."""
+
+    @staticmethod
+    def forward(ctx, fns, counts, *flat):
+        cur = torch.cuda.current_stream()
+        n = len(fns)
+        side = [cur] + [_side_stream(cur.device, i) for i in range(1, n)]
+        for i in range(1, n):
+            _order(cur, side[i])
+        graphs, pos = [], 0
+        for i in range(n):
+            ins = flat[pos:pos + counts[i]]
+            pos += counts[i]
+            with torch.cuda.stream(side[i]), torch.enable_grad():
+                loc = []
+                for t in ins:
+                    if i:
+                        t.record_stream(side[i])
+                    loc.append(t.detach().requires_grad_(True) if (t.requires_grad and t.is_floating_point()) else t)
+                out = fns[i](loc)
+            if not torch.is_tensor(out):
+                raise TypeError("parallel(): every callable must return one tensor")
+            graphs.append((loc, [out]))
+        for i in range(1, n):
+            _order(side[i], cur)
+            for t in graphs[i][1]:
+                t.record_stream(cur)
+        ctx.graphs, ctx.side = graphs, side
+        return tuple(t.detach() for _, outs in graphs for t in outs)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        cur = torch.cuda.current_stream()
+        side = [cur] + list(ctx.side[1:])
+        n = len(side)
+        for i in range(1, n):
+            _order(cur, side[i])
+        grads, pos = [], 0
+        for i, (loc, outs) in enumerate(ctx.graphs):
+            gs = gouts[pos:pos + len(outs)]
+            pos += len(outs)
+            pairs = [(o, g) for o, g in zip(outs, gs) if g is not None and o.requires_grad]
+            with torch.cuda.stream(side[i]):
+                if pairs:
+                    if i:
+                        for _, g in pairs:
+                            g.record_stream(side[i])
+                    torch.autograd.backward([o for o, _ in pairs], [g for _, g in pairs])
+            for t in loc:
+                g = t.grad if (t.requires_grad and t.is_leaf) else None
+                if g is not None and i:
+                    g.record_stream(cur)
+                grads.append(g)
+                if g is not None:
+                    t.grad = None
+        for i in range(1, n):
+            _order(side[i], cur)
+        ctx.graphs = None
+        return (None, None, *grads)
+
+
+def parallel(fns, inputs):
+    """Run fns[0](inputs[0]) on the current stream and fns[i>0](inputs[i]) concurrently on side streams; returns the
+    results (one tensor per callable) in order.  `inputs[i]` is the list of tensors fns[i] reads (everything else it
+    touches must be parameters or tensors it creates itself)."""
     n = len(fns)
     if n == 1 or not streams_enabled() or ops() is not nnops:
-        return [f() for f in fns]
+        return [f(list(x)) for f, x in zip(fns, inputs)]
+    if _REGION[0] and torch.is_grad_enabled():
+        counts = [len(x) for x in inputs]
+        flat = [t for x in inputs for t in x]
+        return list(_Region.apply(fns, counts, *flat))
     cur = torch.cuda.current_stream()
     outs = [None] * n
     side = [None] + [_side_stream(cur.device, i) for i in range(1, n)]
     for i in range(1, n):                     # fork first: side streams depend only on work enqueued before this point
         side[i].wait_stream(cur)
-        if inputs is not None:
-            for t in _tensors(inputs[i]):
-                t.record_stream(side[i])
-    outs[0] = fns[0]()                        # then run in index order, so autograd nodes are created exactly as in the
+        for t in inputs[i]:
+            t.record_stream(side[i])
+    outs[0] = fns[0](list(inputs[0]))         # then run in index order, so autograd nodes are created exactly as in the
     for i in range(1, n):                     # sequential schedule (same backward order, same bf16 accumulation order)
         with torch.cuda.stream(side[i]):
-            outs[i] = fns[i]()
+            outs[i] = fns[i](list(inputs[i]))
     for i in range(1, n):
         cur.wait_stream(side[i])
         for t in _tensors(outs[i]):

@@ -291,6 +291,7 @@ class Trainer:
         # concurrent branch streams: on for eager steps (unless hook-driven comm overlap needs single-stream autograd);
         # inside a captured graph only on request (fork/join capture across streams, see scripts/gpu_graph_streams.py)
         self._want_streams = graph_streams if use_graph else (not overlap_comm)
+        self._region = graph_streams               # with use_graph=False: eager launches, same autograd structure as the graph
         t = cfg.train
         if t.optimizer != "AdamW":
             raise ValueError(f"Unknown optimizer: {t.optimizer}")   # the fused kernel implements the reference default only
@@ -354,6 +355,7 @@ class Trainer:
     def step(self, batch):
         from . import dispatch
         dispatch.set_streams(self._want_streams)
+        dispatch.set_region_mode(self._region)    # capturable fork/join (one autograd node per parallel region)
         if not self.use_graph:
             return self._eager_step(batch)
         if self._graph is None:

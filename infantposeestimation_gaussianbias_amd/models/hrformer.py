@@ -61,10 +61,11 @@ class HRFormerModule(nn.Module):
     def forward(self, xs, scales=None):
         """scales: (n_draws, B) DropPath multipliers for this module (two per block, branch-major), or None."""
         def make(b, blocks, d0):
-            def run():
-                t, d = xs[b], d0
+            def run(ins):
+                t, d = ins[0], d0
+                sc = ins[1] if len(ins) > 1 else None
                 for blk in blocks:
-                    s1, s2 = (scales[d], scales[d + 1]) if scales is not None else (None, None)
+                    s1, s2 = (sc[d], sc[d + 1]) if sc is not None else (None, None)
                     d += 2
                     t = nnops.window_block(t, blk, blk.heads, s1, s2)
                 return t

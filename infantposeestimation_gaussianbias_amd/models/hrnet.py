@@ -20,8 +20,8 @@ class HighResolutionModule(nn.Module):
 
     def forward(self, xs):
         def make(b, blocks):
-            def run():
-                t = xs[b]
+            def run(ins):
+                t = ins[0]
                 for blk in blocks:
                     t = blk(t)
                 return t

@@ -524,7 +524,7 @@ def exchange(xs, fuse, training, n_out=None):
     n = len(xs)
 
     def make(i):
-        def run():
+        def run(xs):
             terms = []
             for j in range(n):
                 if j == i:

@@ -40,6 +40,43 @@ def stage_a():
     print("A: torch fork/join capture ok, max err", float((out - ref).abs().max()), flush=True)
 
 
+def stage_t():
+    """torch-only: autograd ACROSS streams inside a capture (the engine inserts its own events from its worker thread)."""
+    import torch
+    x = torch.randn(512, 512, device="cuda")
+    ws = [torch.randn(512, 512, device="cuda", requires_grad=True) for _ in range(3)]
+    s0, s1, s2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+
+    def fwd_bwd():
+        for w in ws:
+            w.grad = None
+        a = x @ ws[0]
+        s1.wait_stream(s0)
+        s2.wait_stream(s0)
+        with torch.cuda.stream(s1):
+            b = torch.tanh(a @ ws[1])
+        with torch.cuda.stream(s2):
+            c = torch.tanh(a @ ws[2])
+        s0.wait_stream(s1)
+        s0.wait_stream(s2)
+        loss = (b * c).sum()
+        loss.backward()
+        return loss
+
+    with torch.cuda.stream(s0):
+        for _ in range(3):
+            fwd_bwd()
+    torch.cuda.synchronize()
+    ref = [w.grad.clone() for w in ws]
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=s0):
+        fwd_bwd()
+    print("T: captured", flush=True)
+    g.replay()
+    torch.cuda.synchronize()
+    print("T: autograd across streams in capture ok, grad err", [float((w.grad - r).abs().max()) for w, r in zip(ws, ref)], flush=True)
+
+
 def _trainer(graph, streams, B):
     import torch
     from infantposeestimation_gaussianbias_amd import engine
@@ -54,6 +91,36 @@ def _trainer(graph, streams, B):
     model = build_model(cfg).to("cuda")
     model.backbone.drop_path_rate = 0.0
     return engine.Trainer(model, cfg, iters_per_epoch=2, use_graph=graph, graph_warmup=2, graph_streams=streams), batch
+
+
+def stage_v(variant):
+    """Bisect the capture crash: F = forward + loss only, G = fwd+bwd (no optimiser), J = full step + explicit join."""
+    import torch
+    from infantposeestimation_gaussianbias_amd import dispatch
+    tr, batch = _trainer(True, True, 4)
+    full = tr._fwd_bwd
+
+    def fwd_only(b):
+        tr.opt.zero_grad()
+        return tr.model(b["img"], b["target"], b["target_weight"], gt_keypoints=b.get("keypoints"), input_size=tr.cfg.data.input_size)
+
+    def joined(b):
+        out = full(b)
+        dispatch.join_side_streams()
+        return out
+
+    for i in range(2):
+        tr.step(batch)                      # eager warm-up steps (with optimiser)
+    if variant == "F":
+        tr._fwd_bwd = fwd_only
+    elif variant in ("J", "G"):
+        tr._fwd_bwd = joined
+    if variant in ("F", "G"):
+        tr.opt.step = lambda *a, **k: None
+    for i in range(3):
+        out = tr.step(batch)
+        torch.cuda.synchronize()
+        print(variant, "step", i, float(out["loss"].detach()), flush=True)
 
 
 def stage_b():
@@ -86,11 +153,17 @@ def stage_c():
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1:
-        {"A": stage_a, "B": stage_b, "C": stage_c}[sys.argv[1]]()
+    if len(sys.argv) == 2:
+        st = sys.argv[1]
+        if st in "FGJ":
+            stage_v(st)
+        elif st == "T":
+            stage_t()
+        else:
+            {"A": stage_a, "B": stage_b, "C": stage_c}[st]()
         sys.exit(0)
-    for st in "ABC":
+    for st in (sys.argv[2] if len(sys.argv) > 2 else "ABC"):
         r = subprocess.run([sys.executable, os.path.abspath(__file__), st], timeout=400)
         print(f"stage {st}: exit code {r.returncode}", flush=True)
-        if r.returncode != 0 and st != "A":
+        if r.returncode != 0 and st in "BC":
             break

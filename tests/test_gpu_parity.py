@@ -378,6 +378,60 @@ def test_branch_streams_are_bitwise_identical_to_single_stream():
         assert torch.equal(flat, runs[0][1])
 
 
+def test_region_mode_gradients_match_stream_mode():
+    """dispatch.parallel as ONE autograd node (region mode, the capturable variant) gives the same loss and the same
+    parameter gradients as the eager multi-stream variant up to the order in which shared inputs' gradients are added."""
+    from infantposeestimation_gaussianbias_amd import dispatch, engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    batch = synthetic_batch(4, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=11)
+    res = {}
+    try:
+        for region in (False, True):
+            torch.manual_seed(0)
+            model = build_model(cfg).to(DEV)
+            model.backbone.drop_path_rate = 0.0
+            tr = engine.Trainer(model, cfg, iters_per_epoch=2)
+            tr.step(batch)                                   # first step installs the gradient views
+            dispatch.set_streams(True)
+            dispatch.set_region_mode(region)
+            out = tr._fwd_bwd(batch)
+            torch.cuda.synchronize()
+            res[region] = (float(out["loss"].detach()), tr.opt.grad.clone())
+    finally:
+        dispatch.set_region_mode(False)
+    assert math.isclose(res[False][0], res[True][0], rel_tol=1e-6)
+    a, b = res[False][1], res[True][1]
+    assert float((a - b).norm() / a.norm()) < 2e-2           # bf16 re-association of fan-out gradient sums only
+
+
+def test_graph_with_branch_streams_matches_eager_steps():
+    """hipGraph capture WITH concurrent branch streams (region-mode fork/join) follows the loss trajectory of the same
+    autograd structure launched eagerly."""
+    from infantposeestimation_gaussianbias_amd import dispatch, engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    batches = [synthetic_batch(4, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=30 + i) for i in range(3)]
+    traj = {}
+    try:
+        for mode in (False, True):
+            torch.manual_seed(0)
+            model = build_model(cfg).to(DEV)
+            model.backbone.drop_path_rate = 0.0
+            tr = engine.Trainer(model, cfg, iters_per_epoch=2, use_graph=mode, graph_warmup=2, graph_streams=True)
+            traj[mode] = [float(tr.step(batches[i % 3])["loss"].detach()) for i in range(7)]
+            assert (tr._graph is not None) == mode
+    finally:
+        dispatch.set_region_mode(False)
+    assert np.allclose(traj[False], traj[True], rtol=2e-3), traj
+
+
 def _dp_gpu_worker(rank, world, port, q):
     import os
     import sys

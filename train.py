@@ -88,7 +88,7 @@ def main(args):
     out_dir = os.path.join(cfg.train.checkpoint_dir, f"{cfg.exp_name}_{datetime.now().strftime('%Y%m%d_%H%M%S')}")
     loader = build_dataloader(cfg, is_train=True)
     model = build_model(cfg).to(torch.device("cuda", local))
-    trainer = engine.Trainer(model, cfg, iters_per_epoch=len(loader), use_graph=args.graph)
+    trainer = engine.Trainer(model, cfg, iters_per_epoch=len(loader), use_graph=args.graph, graph_streams=args.graph)
     start_epoch, best_ap = 0, 0.0
     if args.resume and os.path.isfile(args.resume):
         ckpt = torch.load(args.resume, map_location="cpu", weights_only=True)

@@ -145,7 +145,8 @@ int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* 
 int pk_window_attn_fwd(const void* qkv, const float* rel_table, void* out, float* lse, int n_windows, int heads, int C, void* stream);
 int pk_window_attn_bwd_groups(int n_windows, int heads);
 int pk_window_attn_bwd_ws_floats(int n_windows, int heads);  /* size of dbias_partial in floats */
-int pk_window_attn_bwd(const void* qkv, const float* rel_table, const void* dout, const float* lse, void* dqkv,
+/* fwd_out = the `out` tensor pk_window_attn_fwd produced for the same qkv (delta_i = sum_e dout[i][e] * out[i][e]). */
+int pk_window_attn_bwd(const void* qkv, const float* rel_table, const void* fwd_out, const void* dout, const float* lse, void* dqkv,
                        float* dbias_partial, float* dtable, int n_windows, int heads, int C, void* stream);
 
 /* ======================= normalisation / elementwise (HBM-bound, NHWC bf16, 16 bytes per lane) ==================== */

@@ -1,124 +1,157 @@
 // Window attention core of the HRFormer block (A1): per (window, head)
 //     P = softmax(scale * Q K^T + relbias[h]),  O = P V            N = 49 tokens (7x7), head_dim d <= 32
-// One 64-lane wave per (window, head): Q/K/V tiles live in LDS, the 49x49 problem is padded to 64x64 MFMA tiles
-// (v_mfma_f32_16x16x32_bf16) and ONLY tile padding is masked (-inf): the reference's zero-pad tokens are real
-// tokens (q=b_q, k=b_k, v=b_v) and take softmax mass (hrformer.py:80-84, no mask).  Softmax reductions run on
-// the accumulator layout with 16-lane xor shuffles.  Backward recomputes P from the saved log-sum-exp and
-// accumulates the relative-position-bias gradient in registers across the windows a workgroup walks
-// (deterministic two-stage reduction, no float atomics).
+// One 64-lane wave per (window, head); the 49x49 problem is padded to 64x64 MFMA tiles (v_mfma_f32_16x16x32_bf16) and
+// ONLY tile padding is masked: the reference's zero-pad tokens are real tokens (q=b_q, k=b_k, v=b_v) and take softmax
+// mass (hrformer.py:80-84, no mask).
+//
+// Register-resident formulation.  The scores are computed TRANSPOSED, S^T = K Q^T, so that in the MFMA accumulator
+// layout a lane owns ONE query i (column l16) and 16 of the 64 keys j (rows 16cj + 4g + r):
+//   * softmax over j is 16 in-lane values + two xor-shuffles (lanes 16 and 32 apart),
+//   * the bf16 probabilities ARE the B-operand fragment of the next MFMA (column i, k = j) if the contraction index is
+//     enumerated in accumulator order: k-slot (g, jj) of K-step s  <->  key j = 16(2s + jj/4) + 4g + jj%4.  The other
+//     operand (V^T, rows = channel e) is read from a row-major LDS tile with the gfx950 transpose read
+//     `ds_read_b64_tr_b16` using the same key enumeration.  P never goes through LDS.
+//   * results come out transposed (O^T: rows = channel, column = token): a lane holds 4 consecutive channels of one token
+//     -> 8-byte global stores.
+// Q/K/V/dO row fragments (row = token, k = channel) are 16-byte global loads in exactly the MFMA A/B layout; only the
+// tiles that are needed with the token index as contraction index are staged in LDS (forward: V, 5 KB per wave instead
+// of 25 KB -> 4x the resident waves).  rel_index(i,j) = A(i) - A(j) + 84 with A(t) = 13*(t/7) + t%7, so the bias lookup
+// needs no division in the inner loop.
+// Backward recomputes P from the saved log-sum-exp in BOTH layouts: pass 1 (S^T, lane = query i) gives delta_i, dS^T,
+// dQ and the relative-position-bias gradient; pass 2 (S, lane = key j) gives dV = P^T dO and dK = dS^T Q.  The bias
+// gradient is accumulated in registers across the windows a workgroup walks (deterministic two-stage reduction after
+// the kernel, no float atomics).
 #include "pk_common.h"
 
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define AT_N 49
 #define AT_WS 7
 #define RP 40   // row pitch (bf16) of [64][32] row-major tiles
-#define TP 72   // row pitch (bf16) of [*][64] tiles indexed by token
 
 __device__ __forceinline__ bf16x8 lds_frag(const uint16_t* base, int row, int pitch, int k0) {
     return *reinterpret_cast<const bf16x8*>(base + row * pitch + k0);
 }
-typedef __attribute__((ext_vector_type(4))) short s16x4;
-// Fragment whose 8 k-values run down the ROWS of a row-major LDS tile (k0 .. k0+31 = rows, col0 + lane&15 = column):
-// two gfx950 transpose reads (ds_read_b64_tr_b16: 4 rows x 16 columns per 16-lane group, delivered column-major).
-__device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int pitch, int k0, int col0, int lane) {
-    const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
-    const uint16_t* a0 = tile + (k0 + 8 * g + q) * pitch + col0 + 4 * pq;
+// All global reads are branch-free `buffer_load_dwordx4` with the out-of-range offset trick (offset >= num_records returns
+// zeros): rows >= 49 and channels >= d cost no branch, so the compiler issues every load of a window back to back and
+// waits once, instead of serialising one HBM latency per conditional load (that was ~25 us per window).
+#define OOB_OFF 0x80000000u
+#define MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptr), 0, 0x7ffffff0, 0x00020000)
+// Row fragment straight from global memory: token row `row`, channels 8g .. 8g+7 (zeros outside the 49 x d slice).
+#define GLB_FRAG(rsrc, ld, d, row, g4) \
+    __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((row) < AT_N && (g4) * 8 < (d)) ? (unsigned)(((row) * (ld) + (g4) * 8) * 2) : OOB_OFF, 0, 0))
+// Fragment (row/column = channel col0 + l16, k = tokens in ACCUMULATOR ORDER for K-step s): slots jj = 0..3 are tokens
+// 32s + 4g + jj, slots 4..7 are tokens 32s + 16 + 4g + (jj-4), read from a row-major [64][RP] token tile.
+// ds_read_b64_tr_b16: within a 16-lane group lane i addresses 4 elements of row (i>>2) at columns 4(i&3).. and receives
+// column i of the 4 x 16 block.
+__device__ __forceinline__ bf16x8 tok_frag(const uint16_t* tile, int s, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15;
+    const uint16_t* a0 = tile + (32 * s + 4 * g + (i >> 2)) * RP + col0 + 4 * (i & 3);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * pitch));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * RP));
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
-__device__ __forceinline__ int rel_index(int i, int j) {
-    const int yi = i / AT_WS, xi = i - yi * AT_WS, yj = j / AT_WS, xj = j - yj * AT_WS;
-    return (yi - yj + AT_WS - 1) * (2 * AT_WS - 1) + (xi - xj + AT_WS - 1);
+__device__ __forceinline__ int rel_a(int t) { return 13 * (t / AT_WS) + t % AT_WS; }   // rel_index(i,j) = rel_a(i) - rel_a(j) + 84
+__device__ __forceinline__ bf16x8 pack_frag(const f32x4 a, const f32x4 b, float m) {
+    const u32x4 v = {pack_bf16x2(a[0] * m, a[1] * m), pack_bf16x2(a[2] * m, a[3] * m), pack_bf16x2(b[0] * m, b[1] * m),
+                     pack_bf16x2(b[2] * m, b[3] * m)};
+    return __builtin_bit_cast(bf16x8, v);
+}
+__device__ __forceinline__ void store4_bf16(uint16_t* dst, const f32x4 v, float m) {
+    uint2 pk;
+    pk.x = pack_bf16x2(v[0] * m, v[1] * m);
+    pk.y = pack_bf16x2(v[2] * m, v[3] * m);
+    *reinterpret_cast<uint2*>(dst) = pk;
 }
 
-// Load a [49][d] slice (row stride ld) into a zero-padded [64][RP] row-major LDS tile (rows >= 49 and channels >= d are zero).
-__device__ __forceinline__ void stage_tile(const uint16_t* __restrict__ g, int ld, int d, uint16_t* rowmajor, int lane) {
-    for (int idx = lane; idx < 64 * 4; idx += 64) {
-        const int row = idx >> 2, ch = idx & 3;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (row < AT_N && ch * 8 < d) v = *reinterpret_cast<const uint4*>(g + (size_t)row * ld + ch * 8);
-        *reinterpret_cast<uint4*>(rowmajor + row * RP + ch * 8) = v;
+// Load a [49][d] slice (row stride ld) into a zero-padded [64][RP] row-major LDS tile (rows >= 49 and channels >= d are zero):
+// TILE_LOAD issues the four 16-byte loads of this lane, TILE_STORE writes them to LDS (call after all loads are issued).
+#define TILE_LOAD(v, rsrc, ld, d, lane)                                                                              \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                                               \
+        const int row_ = ((lane) >> 2) + 16 * k_, ch_ = (lane) & 3;                                                   \
+        v[k_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (row_ < AT_N && ch_ * 8 < (d)) ? (unsigned)((row_ * (ld) + ch_ * 8) * 2) : OOB_OFF, 0, 0); \
     }
-}
+#define TILE_STORE(v, tile, lane)                                                                                    \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                                                 \
+        *reinterpret_cast<u32x4*>((tile) + (((lane) >> 2) + 16 * k_) * RP + ((lane) & 3) * 8) = v[k_];
 
 // ================================================================================================ forward
 __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict__ qkv, const float* __restrict__ table,
                                                      uint16_t* __restrict__ out, float* __restrict__ lse, int heads, int C, int d,
                                                      float scale) {
-    __shared__ __attribute__((aligned(16))) uint16_t sQ[64 * RP], sK[64 * RP], sV[64 * RP], sP[64 * TP];
+    __shared__ __attribute__((aligned(16))) uint16_t sV[64 * RP];
     __shared__ float sBias[176];
     const int lane = threadIdx.x, g4 = lane >> 4, l16 = lane & 15;
     const int w = blockIdx.x / heads, h = blockIdx.x - w * heads;
     const uint16_t* base = qkv + (size_t)w * AT_N * 3 * C + h * d;
-    stage_tile(base, 3 * C, d, sQ, lane);
-    stage_tile(base + C, 3 * C, d, sK, lane);
-    stage_tile(base + 2 * C, 3 * C, d, sV, lane);
-    for (int i = lane; i < 169; i += 64) sBias[i] = table[i * heads + h];
-    __syncthreads();
-
-    f32x4 s[4][4];
+    const auto rq = MAKE_RSRC(base), rk = MAKE_RSRC(base + C), rv = MAKE_RSRC(base + 2 * C);
+    u32x4 tv[4];
+    TILE_LOAD(tv, rv, 3 * C, d, lane);
     bf16x8 qf[4], kf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-        qf[t] = lds_frag(sQ, 16 * t + l16, RP, g4 * 8);
-        kf[t] = lds_frag(sK, 16 * t + l16, RP, g4 * 8);
+        qf[t] = GLB_FRAG(rq, 3 * C, d, 16 * t + l16, g4);
+        kf[t] = GLB_FRAG(rk, 3 * C, d, 16 * t + l16, g4);
     }
+    for (int i = lane; i < 169; i += 64) sBias[i] = table[i * heads + h];
+    TILE_STORE(tv, sV, lane);
+    int aj[4][4];                       // 84 - A(j) for this lane's 16 keys j = 16cj + 4g4 + r (-1: tile padding)
 #pragma unroll
-    for (int ci = 0; ci < 4; ++ci)
-#pragma unroll
-        for (int cj = 0; cj < 4; ++cj)
-            s[ci][cj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ci], kf[cj], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-
-    // softmax over j for the rows i = 16ci + 4*g4 + r this lane shares with its 16-lane group
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
+    for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = 16 * ci + 4 * g4 + r;
-            const int ic = i < AT_N ? i : 0;
-            float v[4], mx = -INFINITY;
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj) {
-                const int j = 16 * cj + l16;
-                v[cj] = (j < AT_N) ? s[ci][cj][r] * scale + sBias[rel_index(ic, j)] : -INFINITY;
-                mx = fmaxf(mx, v[cj]);
-            }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-            float sum = 0.f;
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj) {
-                v[cj] = __expf(v[cj] - mx);
-                sum += v[cj];
-            }
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-            const float inv = 1.f / sum;
-#pragma unroll
-            for (int cj = 0; cj < 4; ++cj) sP[i * TP + 16 * cj + l16] = f32_to_bf16(v[cj] * inv);
-            if (l16 == 0 && i < AT_N && lse) lse[((size_t)w * heads + h) * AT_N + i] = mx + __logf(sum);
+            const int j = 16 * cj + 4 * g4 + r;
+            aj[cj][r] = j < AT_N ? 84 - rel_a(j) : -1;
         }
-    }
     __syncthreads();
+    bf16x8 vt[2][2];                    // V^T fragments [K-step][channel tile]
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int ce = 0; ce < 2; ++ce) vt[s][ce] = tok_frag(sV, s, 16 * ce, lane);
 
-    // O = P V : A = P rows i (k = j); B[k=j][col=e] = V[j][e] read with the transpose read from the row-major V tile
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
-        const bf16x8 p0 = lds_frag(sP, 16 * ci + l16, TP, g4 * 8), p1 = lds_frag(sP, 16 * ci + l16, TP, 32 + g4 * 8);
+        const int i = 16 * ci + l16;
+        const int ai = rel_a(i < AT_N ? i : 0);
+        f32x4 st[4];
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) st[cj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cj], qf[ci], zero, 0, 0, 0);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float bv = sBias[ai + (aj[cj][r] >= 0 ? aj[cj][r] : 0)];      // unconditional load, then select: no branches
+                st[cj][r] = aj[cj][r] >= 0 ? st[cj][r] * scale + bv : -INFINITY;
+                mx = fmaxf(mx, st[cj][r]);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        float sum = 0.f;
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                st[cj][r] = __expf(st[cj][r] - mx);
+                sum += st[cj][r];
+            }
+        sum += __shfl_xor(sum, 16, 64);
+        sum += __shfl_xor(sum, 32, 64);
+        const float inv = 1.f / sum;
+        if (g4 == 0 && i < AT_N && lse) lse[((size_t)w * heads + h) * AT_N + i] = mx + __logf(sum);
+        const bf16x8 p0 = pack_frag(st[0], st[1], inv), p1 = pack_frag(st[2], st[3], inv);
 #pragma unroll
         for (int ce = 0; ce < 2; ++ce) {
             if (ce * 16 >= d) break;
-            f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p0, tr_frag(sV, RP, 0, 16 * ce, lane), (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(p1, tr_frag(sV, RP, 32, 16 * ce, lane), o, 0, 0, 0);
-            const int e = 16 * ce + l16;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ci + 4 * g4 + r;
-                if (i < AT_N && e < d) out[((size_t)w * AT_N + i) * C + h * d + e] = f32_to_bf16(o[r]);
-            }
+            f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[0][ce], p0, zero, 0, 0, 0);
+            o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[1][ce], p1, o, 0, 0, 0);
+            const int e = 16 * ce + 4 * g4;          // this lane: channels e..e+3 of token i
+            if (i < AT_N && e < d) store4_bf16(out + ((size_t)w * AT_N + i) * C + h * d + e, o, 1.f);
         }
     }
 }
@@ -129,7 +162,7 @@ extern "C" int pk_window_attn_fwd(const void* qkv, const float* rel_table, void*
     PK_REQUIRE(C % heads == 0, "pk_window_attn_fwd: C=%d not divisible by heads=%d", C, heads);
     const int d = C / heads;
     PK_SUPPORTED(d <= 32 && (d & 7) == 0, "pk_window_attn_fwd: head_dim %d (supported: multiples of 8 up to 32)", d);
-    PK_REQUIRE((((uintptr_t)qkv) & 15) == 0 && (C & 7) == 0, "pk_window_attn_fwd: alignment");
+    PK_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)out)) & 15) == 0 && (C & 7) == 0, "pk_window_attn_fwd: alignment");
     hipLaunchKernelGGL(k_win_attn_fwd, dim3(n_windows * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv, rel_table,
                        (uint16_t*)out, lse, heads, C, d, 1.f / sqrtf((float)d));
     return pk_launch_status("pk_window_attn_fwd");
@@ -138,177 +171,237 @@ extern "C" int pk_window_attn_fwd(const void* qkv, const float* rel_table, void*
 // ================================================================================================ backward
 // Workgroup g walks windows w = g/heads, g/heads + stride, ... of head h = g % heads; dS is summed in registers and
 // written once to dbias_part[g][49*49].
-__global__ void __launch_bounds__(64) k_win_attn_bwd(const uint16_t* __restrict__ qkv, const float* __restrict__ table,
-                                                     const uint16_t* __restrict__ dout, const float* __restrict__ lse,
-                                                     uint16_t* __restrict__ dqkv, float* __restrict__ dbias_part, int n_windows, int heads,
-                                                     int C, int d, float scale, int wstride) {
-    __shared__ __attribute__((aligned(16))) uint16_t sQ[64 * RP], sK[64 * RP], sV[64 * RP], sdO[64 * RP];
-    __shared__ __attribute__((aligned(16))) uint16_t sP[64 * TP], sdS[64 * TP];     // row-major [i][j]; transposes come from tr reads
+// delta_i = sum_j P_ij dP_ij is taken from the identity delta_i = sum_e dO[i][e] * O[i][e] (O = forward output), so no
+// quantity depends on a whole score row any more: both passes decompose into independent 32-key (pass 1) / 32-query
+// (pass 2) chunks of two accumulator tiles, which keeps ~130 registers live instead of > 256 and lets three waves share a
+// SIMD.  P is recomputed from the saved log-sum-exp in each layout.
+template <int NCE>   // 16-channel tiles of the head dimension (1: d <= 16, 2: d <= 32)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_win_attn_bwd(const uint16_t* __restrict__ qkv, const float* __restrict__ table,
+                                                     const uint16_t* __restrict__ fwd_out, const uint16_t* __restrict__ dout,
+                                                     const float* __restrict__ lse, uint16_t* __restrict__ dqkv,
+                                                     float* __restrict__ dbias_part, int n_windows, int heads, int C, int d, float scale,
+                                                     int wstride) {
+    __shared__ __attribute__((aligned(16))) uint16_t sTiles[3 * 64 * RP];      // Q, K, dO tiles; reused for the bias-gradient fold
+    __shared__ __attribute__((aligned(16))) float sLse[64], sDelta[64];
     __shared__ float sBias[176];
-    const int lane = threadIdx.x, g4 = lane >> 4, l16 = lane & 15;
+    uint16_t *sQ = sTiles, *sK = sTiles + 64 * RP, *sdO = sTiles + 2 * 64 * RP;
+    const int lane0 = threadIdx.x;
     const int h = blockIdx.x % heads;
-    for (int i = lane; i < 169; i += 64) sBias[i] = table[i * heads + h];
-    f32x4 dsum[4][4];
+    for (int i = lane0; i < 169; i += 64) sBias[i] = table[i * heads + h];
+    int a4[4][4];                       // A(t) of the 16 tokens t = 16c + 4g4 + r this lane owns along accumulator rows (-1: padding)
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int t = 16 * c + 4 * (lane0 >> 4) + r;
+            a4[c][r] = t < AT_N ? rel_a(t) : -1;
+        }
+    f32x4 dsum[4][4];                   // [ci][cj][r]: d(bias) at (i = 16ci + l16, j = 16cj + 4g4 + r)
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) dsum[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 
     for (int w = blockIdx.x / heads; w < n_windows; w += wstride) {
         __syncthreads();   // previous iteration's LDS reads are done
         const uint16_t* base = qkv + (size_t)w * AT_N * 3 * C + h * d;
-        stage_tile(base, 3 * C, d, sQ, lane);
-        stage_tile(base + C, 3 * C, d, sK, lane);
-        stage_tile(base + 2 * C, 3 * C, d, sV, lane);
-        stage_tile(dout + (size_t)w * AT_N * C + h * d, C, d, sdO, lane);
-        __syncthreads();
-
-        bf16x8 qf[4], kf[4], vf[4], of[4];
+        const uint16_t* dob = dout + (size_t)w * AT_N * C + h * d;
+        const auto rq = MAKE_RSRC(base), rk = MAKE_RSRC(base + C), rv = MAKE_RSRC(base + 2 * C), rg = MAKE_RSRC(dob);
+        const auto ro = MAKE_RSRC(fwd_out + (size_t)w * AT_N * C + h * d);
+        u32x4 tq[4], tk[4], tg[4], orow[4], grow[4];
+        TILE_LOAD(tq, rq, 3 * C, d, lane0);
+        TILE_LOAD(tk, rk, 3 * C, d, lane0);
+        TILE_LOAD(tg, rg, C, d, lane0);
+        bf16x8 vf[4];                   // V row fragments (token rows, k = channel) straight from global
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
-            qf[t] = lds_frag(sQ, 16 * t + l16, RP, g4 * 8);
-            kf[t] = lds_frag(sK, 16 * t + l16, RP, g4 * 8);
-            vf[t] = lds_frag(sV, 16 * t + l16, RP, g4 * 8);
-            of[t] = lds_frag(sdO, 16 * t + l16, RP, g4 * 8);
+        for (int t = 0; t < 4; ++t) vf[t] = GLB_FRAG(rv, 3 * C, d, 16 * t + (lane0 & 15), lane0 >> 4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {   // token `lane0`: its rows of O and dO for delta = sum_e dO*O
+            const unsigned off = (lane0 < AT_N && c * 8 < d) ? (unsigned)((lane0 * C + c * 8) * 2) : OOB_OFF;
+            orow[c] = __builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0);
+            grow[c] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
         }
+        const float l = lane0 < AT_N ? lse[((size_t)w * heads + h) * AT_N + lane0] : 0.f;
+        TILE_STORE(tq, sQ, lane0);
+        TILE_STORE(tk, sK, lane0);
+        TILE_STORE(tg, sdO, lane0);
+        {
+            float de = 0.f;
 #pragma unroll
-        for (int ci = 0; ci < 4; ++ci) {
-            f32x4 s[4], dp[4];
+            for (int c = 0; c < 4; ++c)
 #pragma unroll
-            for (int cj = 0; cj < 4; ++cj) {
-                s[cj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[ci], kf[cj], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-                dp[cj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(of[ci], vf[cj], (f32x4){0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ci + 4 * g4 + r;
-                const bool iok = i < AT_N;
-                const float l = iok ? lse[((size_t)w * heads + h) * AT_N + i] : 0.f;
-                float p[4], delta = 0.f;
-#pragma unroll
-                for (int cj = 0; cj < 4; ++cj) {
-                    const int j = 16 * cj + l16;
-                    p[cj] = (iok && j < AT_N) ? __expf(s[cj][r] * scale + sBias[rel_index(i, j)] - l) : 0.f;
-                    delta += p[cj] * dp[cj][r];
+                for (int q = 0; q < 4; ++q) {
+                    de += __uint_as_float(orow[c][q] << 16) * __uint_as_float(grow[c][q] << 16);
+                    de += __uint_as_float(orow[c][q] & 0xffff0000u) * __uint_as_float(grow[c][q] & 0xffff0000u);
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) delta += __shfl_xor(delta, o, 64);
-#pragma unroll
-                for (int cj = 0; cj < 4; ++cj) {
-                    const int j = 16 * cj + l16;
-                    const float ds = p[cj] * (dp[cj][r] - delta);
-                    dsum[ci][cj][r] += ds;
-                    sP[i * TP + j] = f32_to_bf16(p[cj]);
-                    sdS[i * TP + j] = f32_to_bf16(ds);
-                }
-            }
+            sLse[lane0] = l;
+            sDelta[lane0] = de;
         }
         __syncthreads();
         uint16_t* dq = dqkv + (size_t)w * AT_N * 3 * C + h * d;
-        // dV = P^T dO, dK = scale * dS^T Q (output rows j: A operands are transpose reads of the row-major P / dS tiles);
-        // dQ = scale * dS K (output rows i: plain row fragments of dS).  B operands Q / K / dO: transpose reads (k runs down rows).
+        // The bias table in LDS and the lane's (i, j) pairs do not change from window to window, so LICM would hoist all
+        // 512 bias lookups out of this loop into registers (it did: 256 VGPRs + 108 AGPRs).  An opaque zero added to the
+        // index keeps the lookups inside the loop.
+        int lz = 0;
+        asm volatile("" : "+v"(lz));
+        const int lane = lane0 + lz, g4 = lane >> 4, l16 = lane & 15;      // (same trick for the per-lane LDS addresses)
+
+        // ---- pass 1: transposed scores, lane = query i:  dS^T, bias gradient, dQ^T = scale * K^T dS^T
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) {
-            const bf16x8 pt0 = tr_frag(sP, TP, 0, 16 * ct, lane), pt1 = tr_frag(sP, TP, 32, 16 * ct, lane);
-            const bf16x8 st0 = tr_frag(sdS, TP, 0, 16 * ct, lane), st1 = tr_frag(sdS, TP, 32, 16 * ct, lane);
-            const bf16x8 ds0 = lds_frag(sdS, 16 * ct + l16, TP, g4 * 8), ds1 = lds_frag(sdS, 16 * ct + l16, TP, 32 + g4 * 8);
+        for (int ci = 0; ci < 4; ++ci) {
+            const int i = 16 * ci + l16;
+            const bool iok = i < AT_N;
+            const int ai = rel_a(iok ? i : 0) + 84 + lz;
+            const float li = sLse[i], di = sDelta[i];
+            const bf16x8 qfi = lds_frag(sQ, i, RP, g4 * 8), ofi = lds_frag(sdO, i, RP, g4 * 8);
+            f32x4 acc[2] = {zero, zero};
 #pragma unroll
-            for (int ce = 0; ce < 2; ++ce) {
-                if (ce * 16 >= d) break;
-                const f32x4 z = (f32x4){0.f, 0.f, 0.f, 0.f};
-                f32x4 dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pt0, tr_frag(sdO, RP, 0, 16 * ce, lane), z, 0, 0, 0);
-                dv = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pt1, tr_frag(sdO, RP, 32, 16 * ce, lane), dv, 0, 0, 0);
-                f32x4 dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st0, tr_frag(sQ, RP, 0, 16 * ce, lane), z, 0, 0, 0);
-                dk = __builtin_amdgcn_mfma_f32_16x16x32_bf16(st1, tr_frag(sQ, RP, 32, 16 * ce, lane), dk, 0, 0, 0);
-                f32x4 dqa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ds0, tr_frag(sK, RP, 0, 16 * ce, lane), z, 0, 0, 0);
-                dqa = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ds1, tr_frag(sK, RP, 32, 16 * ce, lane), dqa, 0, 0, 0);
-                const int e = 16 * ce + l16;
+            for (int s = 0; s < 2; ++s) {
+                f32x4 ds[2];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int t = 16 * ct + 4 * g4 + r;
-                    if (t < AT_N && e < d) {
-                        uint16_t* row = dq + (size_t)t * 3 * C + e;
-                        row[0] = f32_to_bf16(dqa[r] * scale);
-                        row[C] = f32_to_bf16(dk[r] * scale);
-                        row[2 * C] = f32_to_bf16(dv[r]);
+                for (int u = 0; u < 2; ++u) {
+                    const int cj = 2 * s + u;
+                    const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sK, 16 * cj + l16, RP, g4 * 8), qfi, zero, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cj], ofi, zero, 0, 0, 0);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float ev = __expf(sc[r] * scale + sBias[ai - (a4[cj][r] >= 0 ? a4[cj][r] : 0)] - li);
+                        const float pv = (iok && a4[cj][r] >= 0) ? ev : 0.f;      // select after the fact: straight-line code
+                        ds[u][r] = pv * (dp[r] - di);
+                        dsum[ci][cj][r] += ds[u][r];
                     }
+                }
+                const bf16x8 df = pack_frag(ds[0], ds[1], 1.f);
+#pragma unroll
+                for (int ce = 0; ce < NCE; ++ce)
+                    acc[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sK, s, 16 * ce, lane), df, acc[ce], 0, 0, 0);
+            }
+#pragma unroll
+            for (int ce = 0; ce < NCE; ++ce) {
+                const int e = 16 * ce + 4 * g4;
+                if (iok && e < d) store4_bf16(dq + (size_t)i * 3 * C + e, acc[ce], scale);
+            }
+        }
+
+        // ---- pass 2: plain scores, lane = key j:  dV^T = dO^T P,  dK^T = scale * Q^T dS
+#pragma unroll
+        for (int cj = 0; cj < 4; ++cj) {
+            const int j = 16 * cj + l16;
+            const bool jok = j < AT_N;
+            const int ajn = 84 - rel_a(jok ? j : 0) + lz;
+            const bf16x8 kfj = lds_frag(sK, j, RP, g4 * 8);
+            f32x4 dv[2] = {zero, zero}, dk[2] = {zero, zero};
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                f32x4 pp[2], ds[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int ci = 2 * s + u;
+                    const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sQ, 16 * ci + l16, RP, g4 * 8), kfj, zero, 0, 0, 0);
+                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sdO, 16 * ci + l16, RP, g4 * 8), vf[cj], zero, 0, 0, 0);
+                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sLse[16 * ci + 4 * g4]);
+                    const f32x4 de4 = *reinterpret_cast<const f32x4*>(&sDelta[16 * ci + 4 * g4]);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float ev = __expf(sc[r] * scale + sBias[(a4[ci][r] >= 0 ? a4[ci][r] : 0) + ajn] - l4[r]);
+                        const float pv = (jok && a4[ci][r] >= 0) ? ev : 0.f;
+                        pp[u][r] = pv;
+                        ds[u][r] = pv * (dp[r] - de4[r]);
+                    }
+                }
+                const bf16x8 pf = pack_frag(pp[0], pp[1], 1.f), df = pack_frag(ds[0], ds[1], 1.f);
+#pragma unroll
+                for (int ce = 0; ce < NCE; ++ce) {
+                    dv[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sdO, s, 16 * ce, lane), pf, dv[ce], 0, 0, 0);
+                    dk[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sQ, s, 16 * ce, lane), df, dk[ce], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int ce = 0; ce < NCE; ++ce) {
+                const int e = 16 * ce + 4 * g4;
+                if (jok && e < d) {
+                    store4_bf16(dq + (size_t)j * 3 * C + C + e, dk[ce], scale);
+                    store4_bf16(dq + (size_t)j * 3 * C + 2 * C + e, dv[ce], 1.f);
                 }
             }
         }
     }
-    float* dst = dbias_part + (size_t)blockIdx.x * AT_N * AT_N;
+    // Fold the register-resident [49][49] bias gradient onto the 169 table entries inside the workgroup (fixed summation
+    // order -> deterministic): the partial result per workgroup is 169 floats instead of 2401.
+    __syncthreads();
+    float* sD = reinterpret_cast<float*>(sTiles);            // 49*49*4 = 9604 B <= 15360 B
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ci + 4 * g4 + r, j = 16 * cj + l16;
-                if (i < AT_N && j < AT_N) dst[i * AT_N + j] = dsum[ci][cj][r];
+                const int i = 16 * ci + (lane0 & 15), j = 16 * cj + 4 * (lane0 >> 4) + r;
+                if (i < AT_N && j < AT_N) sD[i * AT_N + j] = dsum[ci][cj][r];
             }
+    __syncthreads();
+    for (int e = lane0; e < 169; e += 64) {
+        const int dy = e / 13 - 6, dx = e % 13 - 6;
+        float acc = 0.f;
+        for (int yj = 0; yj < AT_WS; ++yj) {
+            const int yi = yj + dy;
+            if (yi < 0 || yi >= AT_WS) continue;
+            for (int xj = 0; xj < AT_WS; ++xj) {
+                const int xi = xj + dx;
+                if (xi < 0 || xi >= AT_WS) continue;
+                acc += sD[(yi * AT_WS + xi) * AT_N + yj * AT_WS + xj];
+            }
+        }
+        dbias_part[(size_t)blockIdx.x * 169 + e] = acc;
+    }
 }
 
-// Relative-position-bias gradient, two deterministic stages:
-//   A) tmp[h][i*49+j] = sum over the workgroups of head h of their register-accumulated dS (coalesced over ij)
-//   B) dtable[e][h]   = sum over the <= 49 (i,j) pairs with rel_index(i,j) == e
-__global__ void __launch_bounds__(256) k_relbias_reduce(const float* __restrict__ part, int n_groups, int heads, float* __restrict__ tmp) {
-    // block = 16 (i,j) entries x 16 group-lanes; fixed-order combine (deterministic), chain length n_groups/(16*heads)
+// Relative-position-bias gradient, second stage: dtable[e][h] = sum over the workgroups g of head h (g % heads == h) of
+// part[g][e].  Block = 16 table entries x 16 group-lanes, fixed-order combine (deterministic, no float atomics).
+__global__ void __launch_bounds__(256) k_relbias_reduce(const float* __restrict__ part, int n_groups, int heads, float* __restrict__ dtable) {
     __shared__ float sh[16][17];
     const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int ij = blockIdx.x * 16 + col, h = blockIdx.y;
+    const int e = blockIdx.x * 16 + col, h = blockIdx.y;
     float s = 0.f;
-    if (ij < AT_N * AT_N)
-        for (int g = h + rl * heads; g < n_groups; g += 16 * heads) s += part[(size_t)g * AT_N * AT_N + ij];
+    if (e < 169)
+        for (int g = h + rl * heads; g < n_groups; g += 16 * heads) s += part[(size_t)g * 169 + e];
     sh[rl][col] = s;
     __syncthreads();
-    if (rl != 0 || ij >= AT_N * AT_N) return;
+    if (rl != 0 || e >= 169) return;
     s = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) s += sh[r][col];
-    tmp[(size_t)h * AT_N * AT_N + ij] = s;
-}
-__global__ void __launch_bounds__(256) k_relbias_scatter(const float* __restrict__ tmp, int heads, float* __restrict__ dtable) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 169 * heads) return;
-    const int e = t / heads, h = t - e * heads;
-    const int dy = e / 13 - 6, dx = e % 13 - 6;
-    const float* p = tmp + (size_t)h * AT_N * AT_N;
-    float s = 0.f;
-    for (int yj = 0; yj < AT_WS; ++yj) {
-        const int yi = yj + dy;
-        if (yi < 0 || yi >= AT_WS) continue;
-        for (int xj = 0; xj < AT_WS; ++xj) {
-            const int xi = xj + dx;
-            if (xi < 0 || xi >= AT_WS) continue;
-            s += p[(yi * AT_WS + xi) * AT_N + yj * AT_WS + xj];
-        }
-    }
-    dtable[t] = s;
+    dtable[e * heads + h] = s;
 }
 
 extern "C" int pk_window_attn_bwd_groups(int n_windows, int heads) {
-    // one 64-lane workgroup per (window-group, head); aim for >= 1024 workgroups so every CU holds several waves
-    int per_head = (1024 + heads - 1) / heads;
-    if (per_head < 64) per_head = 64;
-    if (per_head > n_windows) per_head = n_windows;
+    // One 64-lane workgroup per (window-group, head).  The kernel holds 2 waves per SIMD (2048 on the chip): give every
+    // workgroup ceil(total / 2048) windows so the whole problem is resident at once and no workgroup walks more than that.
+    const long total = (long)n_windows * heads;
+    const int wpg = (int)((total + 2047) / 2048);
+    const int per_head = (n_windows + wpg - 1) / wpg;
     return per_head * heads;
 }
-extern "C" int pk_window_attn_bwd_ws_floats(int n_windows, int heads) {
-    return (pk_window_attn_bwd_groups(n_windows, heads) + heads) * AT_N * AT_N;
-}
-extern "C" int pk_window_attn_bwd(const void* qkv, const float* rel_table, const void* dout, const float* lse, void* dqkv,
-                                  float* dbias_partial, float* dtable, int n_windows, int heads, int C, void* stream) {
-    PK_REQUIRE(qkv && rel_table && dout && lse && dqkv && dbias_partial && dtable, "pk_window_attn_bwd: null pointer");
+extern "C" int pk_window_attn_bwd_ws_floats(int n_windows, int heads) { return pk_window_attn_bwd_groups(n_windows, heads) * 169; }
+extern "C" int pk_window_attn_bwd(const void* qkv, const float* rel_table, const void* fwd_out, const void* dout, const float* lse,
+                                  void* dqkv, float* dbias_partial, float* dtable, int n_windows, int heads, int C, void* stream) {
+    PK_REQUIRE(qkv && rel_table && fwd_out && dout && lse && dqkv && dbias_partial && dtable, "pk_window_attn_bwd: null pointer");
+    PK_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)fwd_out) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) == 0 && (C & 7) == 0,
+               "pk_window_attn_bwd: alignment");
     PK_REQUIRE(n_windows > 0 && heads > 0 && C > 0 && C % heads == 0, "pk_window_attn_bwd: bad sizes");
     const int d = C / heads;
     PK_SUPPORTED(d <= 32 && (d & 7) == 0, "pk_window_attn_bwd: head_dim %d", d);
     const int groups = pk_window_attn_bwd_groups(n_windows, heads);
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(k_win_attn_bwd, dim3(groups), dim3(64), 0, st, (const uint16_t*)qkv, rel_table, (const uint16_t*)dout, lse,
-                       (uint16_t*)dqkv, dbias_partial, n_windows, heads, C, d, 1.f / sqrtf((float)d), groups / heads);
-    // stage-A output reuses the tail of the partial buffer (caller sizes it for groups + heads tiles)
-    float* tmp = dbias_partial + (size_t)groups * AT_N * AT_N;
-    hipLaunchKernelGGL(k_relbias_reduce, dim3((AT_N * AT_N + 15) / 16, heads), dim3(256), 0, st, dbias_partial, groups, heads, tmp);
-    hipLaunchKernelGGL(k_relbias_scatter, dim3((169 * heads + 255) / 256), dim3(256), 0, st, tmp, heads, dtable);
+    if (d > 16)
+        hipLaunchKernelGGL(k_win_attn_bwd<2>, dim3(groups), dim3(64), 0, st, (const uint16_t*)qkv, rel_table, (const uint16_t*)fwd_out,
+                           (const uint16_t*)dout, lse, (uint16_t*)dqkv, dbias_partial, n_windows, heads, C, d, 1.f / sqrtf((float)d),
+                           groups / heads);
+    else
+        hipLaunchKernelGGL(k_win_attn_bwd<1>, dim3(groups), dim3(64), 0, st, (const uint16_t*)qkv, rel_table, (const uint16_t*)fwd_out,
+                           (const uint16_t*)dout, lse, (uint16_t*)dqkv, dbias_partial, n_windows, heads, C, d, 1.f / sqrtf((float)d),
+                           groups / heads);
+    hipLaunchKernelGGL(k_relbias_reduce, dim3((169 + 15) / 16, heads), dim3(256), 0, st, dbias_partial, groups, heads, dtable);
     return pk_launch_status("pk_window_attn_bwd");
 }

@@ -72,8 +72,11 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 
 // ---- bf16 <-> f32 ----------------------------------------------------------------------------------------
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float(((uint32_t)h) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {  // round-to-nearest-even, NaN stays NaN
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
-    return (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// fp32 -> bf16, round-to-nearest-even, NaN stays NaN: gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two
+// values per instruction); the integer bit trick costs ~6 VALU instructions per value and dominated the epilogues.
+typedef __attribute__((ext_vector_type(2))) float pk_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 pk_bf16x2;
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((pk_f32x2){lo, hi}, pk_bf16x2));
 }

@@ -92,7 +92,6 @@ __device__ __forceinline__ int swz(int row) { return BK == 64 ? ((row >> 1) & 7)
 // (the MFMA C layout would give 8-byte pieces of 16 different rows per instruction), and (b) the epilogue is ONE rolled
 // loop: unrolled per accumulator tile it was ~2000 instructions x 16 tiles (erff inlined 64 times, 250 KB of code for
 // one kernel), which made the K=32 GEMMs instruction-fetch bound.  Only static indexing of v[] (no scratch).
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) { return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16); }
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 

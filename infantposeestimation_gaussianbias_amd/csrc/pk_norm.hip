@@ -13,10 +13,10 @@ __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
 }
 __device__ __forceinline__ uint4 pack8(const float* f) {
     uint4 v;
-    v.x = (uint32_t)f32_to_bf16(f[0]) | ((uint32_t)f32_to_bf16(f[1]) << 16);
-    v.y = (uint32_t)f32_to_bf16(f[2]) | ((uint32_t)f32_to_bf16(f[3]) << 16);
-    v.z = (uint32_t)f32_to_bf16(f[4]) | ((uint32_t)f32_to_bf16(f[5]) << 16);
-    v.w = (uint32_t)f32_to_bf16(f[6]) | ((uint32_t)f32_to_bf16(f[7]) << 16);
+    v.x = pack_bf16x2(f[0], f[1]);
+    v.y = pack_bf16x2(f[2], f[3]);
+    v.z = pack_bf16x2(f[4], f[5]);
+    v.w = pack_bf16x2(f[6], f[7]);
     return v;
 }
 

@@ -32,8 +32,8 @@ __global__ void __launch_bounds__(256) k_adamw(float* __restrict__ p, const floa
         reinterpret_cast<float4*>(v)[i] = V;
         if (pb) {
             uint2 o;
-            o.x = (uint32_t)f32_to_bf16(P.x) | ((uint32_t)f32_to_bf16(P.y) << 16);
-            o.y = (uint32_t)f32_to_bf16(P.z) | ((uint32_t)f32_to_bf16(P.w) << 16);
+            o.x = pack_bf16x2(P.x, P.y);
+            o.y = pack_bf16x2(P.z, P.w);
             reinterpret_cast<uint2*>(pb)[i] = o;
         }
     }

@@ -413,7 +413,7 @@ class _AttnHalf(torch.autograd.Function):
         dqkv = _e((Mw, 3 * C), BF16, dev)
         part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads),), F32, dev)
         dtable, s_t = _sink(ptab)
-        call("pk_window_attn_bwd", qkv, table, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, stream_ptr())
+        call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, stream_ptr())
         # qkv linear: scatter the token gradients back to pixel rows (pad tokens dropped)
         du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
         dst, s_wq = _sink(pwqkv)

@@ -109,7 +109,7 @@ def attn_cases(flt):
         dqkv = torch.empty_like(qkv)
         part = torch.empty(lib.pk_window_attn_bwd_ws_floats(nw, heads), device=DEV)
         dt = torch.empty(169, heads, device=DEV)
-        sec = timeit(lambda: call("pk_window_attn_bwd", qkv, table, go, lse, dqkv, part, dt, nw, heads, C, stream_ptr()))
+        sec = timeit(lambda: call("pk_window_attn_bwd", qkv, table, o, go, lse, dqkv, part, dt, nw, heads, C, stream_ptr()))
         report(name + " bwd", sec, 2.5 * flops, (2 * qkv.numel() + go.numel()) * 2)
 
 

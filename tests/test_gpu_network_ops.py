@@ -267,7 +267,7 @@ def test_window_attention_core(N, heads, Cc, nw):
     dqkv = torch.empty(nw * 49, 3 * Cc, device=DEV, dtype=BF)
     part = torch.empty(lib.pk_window_attn_bwd_ws_floats(nw, heads), device=DEV)
     dtab = torch.empty(169, heads, device=DEV)
-    call("pk_window_attn_bwd", qkv.to(DEV, BF), table.to(DEV), go.to(DEV, BF), lse, dqkv, part, dtab, nw, heads, Cc, stream_ptr())
+    call("pk_window_attn_bwd", qkv.to(DEV, BF), table.to(DEV), o, go.to(DEV, BF), lse, dqkv, part, dtab, nw, heads, Cc, stream_ptr())
     assert err(C(dqkv), qr.grad) < 2e-2
     assert err(C(dtab), tr.grad) < 2e-2
 

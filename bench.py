@@ -61,9 +61,18 @@ def roofline_of_dominant_kernel(model):
         sec = time_kernel(lambda: nnops._conv_raw(x, wf, conv.weight.shape[0], 3, 1, True))
     flops = 2.0 * B * H * W * conv.weight.shape[0] * 9 * C
     achieved = flops / sec / 1e12
+    # HBM/fabric bytes per launch of this kernel: PMC counters need rocprofv3, so they are collected offline
+    # (scripts/gpu_pmc_traffic.sh, separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) and committed
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_head_conv_traffic.json")) as f:
+            traffic = round(json.load(f)["traffic_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        pass
     return {"kernel": "k_igemm2<128,2,2,64> (head conv3x3 256->256 @64x48, fwd + BN-stat epilogue)", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-            "traffic": None, "us_per_launch": round(sec * 1e6, 1), "algorithmic_flops": flops}
+            "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss traffic incl. Infinity-Cache hits; algorithmic 202.5e6)",
+            "us_per_launch": round(sec * 1e6, 1), "algorithmic_flops": flops}
 
 
 def cpu_baseline():

@@ -45,6 +45,7 @@ struct IgemmArgs {
     int rows_per_sample;      // rows of one sample (for res_scale): Ho*Wo or tokens per image
     int act;                  // 0 none, 1 GELU(erf), 2 softplus
     int out_mode;             // 0 bf16 row-major, 1 fp32 row-major, 2 fp32 NCHW planes [B][N][Ho*Wo]
+    int xcd_remap;            // set by igemm_launch (PK_IGEMM_XCD=0 disables the XCD-contiguous tile order)
     int vec8;                 // set by igemm_launch: row-major pointers 16-byte aligned and ldo % 8 == 0 -> 16-byte epilogue I/O
 };
 
@@ -198,7 +199,20 @@ __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    // XCD-aware tile order.  Workgroups are handed to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB
+    // L2: with the plain mapping the two N-tiles of one pixel tile (same input!) and the halo-sharing neighbours of a
+    // 3x3 conv land on different L2s (measured: 11x the input bytes cross the fabric for the 256->256 head conv).  Give
+    // every XCD one contiguous chunk of the tile sequence, N-tile index fastest.
+    int mt = blockIdx.x, nt = blockIdx.y;
+    {
+        const int G = gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
+        if ((G & 7) == 0 && p.xcd_remap) {
+            const int tile = (L & 7) * (G >> 3) + (L >> 3);
+            mt = tile / (int)gridDim.y;
+            nt = tile - mt * (int)gridDim.y;
+        }
+    }
+    const int m0 = mt * BM, n0 = nt * BN;
     const bool linear = (p.T == 1 && p.Ho == 0);
     const int kw_n = (p.T == 9) ? 3 : 1;
     const int kc = tid % CH;                         // this thread's chunk column (same for all its rows: 256 % CH == 0)
@@ -364,7 +378,7 @@ __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
                 s += sStat[(w * BN + tid) * 2];
                 q += sStat[(w * BN + tid) * 2 + 1];
             }
-            float* dst = p.stats + (size_t)blockIdx.x * 2 * p.N;
+            float* dst = p.stats + (size_t)mt * 2 * p.N;
             dst[n0 + tid] = s;
             dst[p.N + n0 + tid] = q;
         }
@@ -410,6 +424,8 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     IgemmArgs a = a_in;
     a.vec8 = (a.ldo % 8) == 0 &&
              ((((uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.preact | (uintptr_t)a.gelu_of) & 15) == 0);
+    static const int xcd_on = getenv("PK_IGEMM_XCD") ? atoi(getenv("PK_IGEMM_XCD")) : 1;
+    a.xcd_remap = xcd_on;
     const dim3 block(256);
     const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
     const bool k64 = (a.Cin % 64) == 0;              // deeper K-chunks when the channel count allows full 64-wide tiles

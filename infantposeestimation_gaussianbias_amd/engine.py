@@ -316,6 +316,8 @@ class Trainer:
         out = self.model(batch["img"], batch["target"], batch["target_weight"], gt_keypoints=batch.get("keypoints"),
                          input_size=self.cfg.data.input_size)
         out["loss"].backward()
+        from . import dispatch
+        dispatch.join_aux()            # weight-gradient kernels issued on auxiliary streams (dispatch.aux_stream_for)
         return out
 
     def _eager_step(self, batch):

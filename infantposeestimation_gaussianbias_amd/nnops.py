@@ -193,9 +193,17 @@ def _conv_dgrad(g, wd, Cin, ksize, stride, in_hw):
 
 
 def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=None, g_rps=0, M=None, oihw=True, out=None,
-           dbias=None):
+           dbias=None, deferred=False):
     """-> fp32 gradient (N, Cin, k, k) for conv (geom=(B,Hs,Ws,Ho,Wo)) or (N, Cin) for linear (geom=None); `out` = destination.
-    `dbias` (fp32, <= N entries) additionally receives the bias gradient (column sums of the same scaled/gathered rows)."""
+    `dbias` (fp32, <= N entries) additionally receives the bias gradient (column sums of the same scaled/gathered rows).
+    `deferred=True` (only when every output is a gradient sink, i.e. nothing downstream in backward reads the result): the
+    kernels go to the auxiliary weight-gradient stream of the current stream (dispatch.aux_stream_for / join_aux)."""
+    if deferred and out is not None:
+        from . import dispatch
+        if dispatch.aux_wgrad_enabled():
+            aux = dispatch.aux_stream_for(torch.cuda.current_stream(), (x, g, a_map, g_map, g_scale))
+            with torch.cuda.stream(aux):
+                return _wgrad(x, g, N, Cin, ksize, stride, geom, a_map, g_map, g_scale, g_rps, M, oihw, out, dbias, False)
     T = ksize * ksize
     if geom is None:
         B = Hs = Ws = Ho = Wo = 0
@@ -272,7 +280,7 @@ class _ConvBnAct(torch.autograd.Function):
                 dw = None
         else:
             dst, sw = _sink(w_p)
-            dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo), out=dst)
+            dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo), out=dst, deferred=sw)
             dw = None if sw else dw
         return dx, dw, None if sg else dgamma, None if sb else dbeta, dres, None, None, None, None
 
@@ -408,7 +416,8 @@ class _AttnHalf(torch.autograd.Function):
         d_o = _linear(dy2, wproj_t, Mw, C, C, res_scale=s1, a_map=amap, rps=nwin * WS * WS)
         dst, s_wp = _sink(pwproj)
         dbproj, s_bp = _sink(pbproj)
-        dwproj = _wgrad(o, dy2, C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw, out=dst, dbias=dbproj)
+        dwproj = _wgrad(o, dy2, C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw, out=dst, dbias=dbproj,
+                        deferred=s_wp and s_bp)
         # attention core
         dqkv = _e((Mw, 3 * C), BF16, dev)
         part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads),), F32, dev)
@@ -418,7 +427,7 @@ class _AttnHalf(torch.autograd.Function):
         du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
         dst, s_wq = _sink(pwqkv)
         dbqkv, s_bq = _sink(pbqkv)
-        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw, out=dst, dbias=dbqkv)
+        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw, out=dst, dbias=dbqkv, deferred=s_wq and s_bq)
         dx, dg1, db1 = _layernorm_bwd(du, x2, mean, rstd, g1, dy2, pg1, pb1)
         return (dx.view(B, H, W, C), dg1, db1, None if s_t else dtable, None if s_wq else dwqkv, None if s_bq else dbqkv,
                 None if s_wp else dwproj, None if s_bp else dbproj, None, None)
@@ -455,11 +464,11 @@ class _MlpHalf(torch.autograd.Function):
         dz = _linear(dy2, w2_t, M, Hd, C, res_scale=s2, gelu_of=z, rps=H * W)        # (dy W2) * s2 * gelu'(z)
         dst, s_w2 = _sink(pw2)
         db2, s_b2 = _sink(pbias2)
-        dw2 = _wgrad(h, dy2, C, Hd, 1, 1, None, g_scale=s2, g_rps=H * W, M=M, out=dst, dbias=db2)
+        dw2 = _wgrad(h, dy2, C, Hd, 1, 1, None, g_scale=s2, g_rps=H * W, M=M, out=dst, dbias=db2, deferred=s_w2 and s_b2)
         dv = _linear(dz, w1_t, M, C, Hd)
         dst, s_w1 = _sink(pw1)
         db1, s_b1 = _sink(pbias1)
-        dw1 = _wgrad(v, dz, Hd, C, 1, 1, None, M=M, out=dst, dbias=db1)
+        dw1 = _wgrad(v, dz, Hd, C, 1, 1, None, M=M, out=dst, dbias=db1, deferred=s_w1 and s_b1)
         dx, dg2, dbt2 = _layernorm_bwd(dv, x2, mean, rstd, g2, dy2, pg2, pb2)
         return (dx.view(B, H, W, C), dg2, dbt2, None if s_w1 else dw1, None if s_b1 else db1, None if s_w2 else dw2,
                 None if s_b2 else db2, None)

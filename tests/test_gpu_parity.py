@@ -432,7 +432,7 @@ def test_graph_with_branch_streams_matches_eager_steps():
     assert np.allclose(traj[False], traj[True], rtol=2e-3), traj
 
 
-def _dp_gpu_worker(rank, world, port, q):
+def _dp_gpu_worker(rank, world, port, q, use_graph=False):
     import os
     import sys
     import torch.distributed as dist
@@ -449,8 +449,17 @@ def _dp_gpu_worker(rank, world, port, q):
     torch.manual_seed(rank)                                  # ranks start from DIFFERENT weights: broadcast repairs it
     model = build_model(cfg).to("cuda")
     model.backbone.drop_path_rate = 0.0
-    tr = engine.Trainer(model, cfg, iters_per_epoch=2)
+    tr = engine.Trainer(model, cfg, iters_per_epoch=2, use_graph=use_graph, graph_warmup=1, graph_streams=use_graph)
     init = tr.opt.flat.clone()
+    if use_graph:
+        # step 1 eager (warm-up), step 2 captures forward+backward (RCCL/gloo and AdamW stay outside the graph) and replays
+        losses = [float(tr.step(shard)["loss"].detach()) for _ in range(3)]
+        torch.cuda.synchronize()
+        assert tr._graph is not None and not tr._graph_has_opt
+        q.put((rank, init.cpu().numpy(), np.asarray(losses), tr.opt.grad.cpu().numpy(), tr.opt.flat.cpu().numpy(), losses[-1]))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     # local gradient of this shard from the broadcast weights, no exchange
     world_saved, tr.comm.world = tr.comm.world, 1
     tr._fwd_bwd(shard)
@@ -466,9 +475,7 @@ def _dp_gpu_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_trainer_data_parallel_two_ranks_one_gpu():
-    """World-size-2 Trainer step (gloo carrying the HIP-produced flat gradient): summed gradient == sum of the ranks'
-    local gradients, and both ranks hold identical weights before and after the step (reference: DDP in train.py)."""
+def _run_two_ranks(use_graph):
     import socket
     import torch.multiprocessing as mp
     with socket.socket() as s:
@@ -476,14 +483,31 @@ def test_trainer_data_parallel_two_ranks_one_gpu():
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q, use_graph)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
-    (_, i0, l0, g0, f0, loss0), (_, i1, l1, g1, f1, loss1) = res
+    return res
+
+
+def test_trainer_data_parallel_graph_replay_two_ranks_one_gpu():
+    """N>1 graph mode: the captured hipGraph holds zero_grad+forward+backward only; the gradient exchange and AdamW run
+    eagerly between replays.  Both ranks must hold identical summed gradients and weights after three steps, and the
+    loss must move (the optimiser really ran on the replayed gradients)."""
+    (_, i0, l0, g0, f0, _), (_, i1, l1, g1, f1, _) = _run_two_ranks(True)
+    assert np.array_equal(i0, i1)
+    assert np.array_equal(g0, g1) and np.array_equal(f0, f1)
+    assert not np.array_equal(f0, i0)
+    assert np.all(np.isfinite(l0)) and np.all(np.isfinite(l1)) and l0[2] != l0[0]
+
+
+def test_trainer_data_parallel_two_ranks_one_gpu():
+    """World-size-2 Trainer step (gloo carrying the HIP-produced flat gradient): summed gradient == sum of the ranks'
+    local gradients, and both ranks hold identical weights before and after the step (reference: DDP in train.py)."""
+    (_, i0, l0, g0, f0, loss0), (_, i1, l1, g1, f1, loss1) = _run_two_ranks(False)
     assert np.array_equal(i0, i1)                                    # broadcast of rank 0's initial state
     assert np.array_equal(g0, g1) and np.array_equal(f0, f1)         # same summed gradient, same updated weights
     assert np.array_equal(g0, l0 + l1)                               # the exchange is an exact two-term sum

@@ -705,10 +705,12 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 static inline int wgrad_tile(int N, int Cin) { return (N >= 128 && Cin >= 128) ? 128 : 64; }
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
     // enough workgroups to fill 256 CUs several times over (>= 2048), but no slice shorter than 256 rows
+    static const int target = getenv("PK_WGRAD_WGS") ? atoi(getenv("PK_WGRAD_WGS")) : 2048;
+    static const int min_rows = getenv("PK_WGRAD_ROWS") ? atoi(getenv("PK_WGRAD_ROWS")) : 256;
     const int tl = wgrad_tile(N, Cin);
     const int tiles = ((N + tl - 1) / tl) * ((Cin + tl - 1) / tl) * T;
-    int s = (2048 + tiles - 1) / tiles;
-    const int max_s = (M + 255) / 256;
+    int s = (target + tiles - 1) / tiles;
+    const int max_s = (M + min_rows - 1) / min_rows;
     if (s > max_s) s = max_s;
     if (s < 1) s = 1;
     if (s > 512) s = 512;

@@ -560,8 +560,11 @@ __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict
         pix /= Ws;
         const int ys = (int)(pix % Hs), b = (int)(pix / Hs);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        const int oy_lo = max(0, (ys - 1) * ry - ry), oy_hi = min(H, (ys + 2) * ry + ry);
-        const int ox_lo = max(0, (xs - 1) * rx - rx), ox_hi = min(W, (xs + 2) * rx + rx);
+        // support of source pixel ys: outputs whose source coordinate (oy + .5) * Hs/H - .5 lies in (ys-1, ys+1), i.e.
+        // oy in ((ys-.5)*H/Hs - .5, (ys+1.5)*H/Hs - .5); H/Hs <= ry, one extra row each side covers non-integer ratios.
+        // (The border clamps only move outputs that are already inside this range.)
+        const int oy_lo = max(0, (ys - 1) * ry - 1), oy_hi = min(H, (ys + 2) * ry + 1);
+        const int ox_lo = max(0, (xs - 1) * rx - 1), ox_hi = min(W, (xs + 2) * rx + 1);
         for (int oy = oy_lo; oy < oy_hi; ++oy) {
             int y0, y1;
             float fy;

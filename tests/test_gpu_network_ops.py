@@ -339,6 +339,15 @@ def test_fuse_sum_and_upsample_backward(N):
     a, b = rnd(1, 8, 9, 7, seed=6), rnd(1, 8, 5, 4, seed=7)
     ref2 = a + F.interpolate(b, size=[9, 7], mode="bilinear", align_corners=False)
     assert err(nchw(N.fuse_sum([nhwc(a), nhwc(b)], False)), ref2) < 8e-3
+    # ... and their backward (non-integer ratios 9/5, 7/4 and 11/3: the gather window of k_upsample_bwd must still cover them)
+    for (Hh, Wh, Hl, Wl) in ((9, 7, 5, 4), (11, 11, 3, 3)):
+        a, b = rnd(1, 8, Hh, Wh, seed=8), rnd(1, 8, Hl, Wl, seed=9)
+        br = b.clone().requires_grad_(True)
+        g2 = rnd(1, 8, Hh, Wh, seed=10)
+        (a + F.interpolate(br, size=[Hh, Wh], mode="bilinear", align_corners=False)).backward(g2)
+        ad, bd = nhwc(a).requires_grad_(True), nhwc(b).requires_grad_(True)
+        N.fuse_sum([ad, bd], False).backward(nhwc(g2))
+        assert err(nchw(bd.grad), br.grad) < 1e-2
 
 
 @pytest.mark.parametrize("name,salt", [("fm2", 9), ("basic", 3)])

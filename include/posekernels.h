@@ -142,12 +142,15 @@ int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* 
 
 /* window attention core (models/hrformer.py:183-196): softmax(scale*q k^T + table[index]) v per (window, head);
  * qkv (n_windows*49, 3C) bf16 in the reference's channel order s*C + h*d + e; rel_table (169, heads) fp32.          */
-int pk_window_attn_fwd(const void* qkv, const float* rel_table, void* out, float* lse, int n_windows, int heads, int C, void* stream);
+/* head_dim d = C/heads: multiple of 8, <= 64.  softmax_scale <= 0 selects the reference's d^-0.5 (hrformer.py:140); a
+ * caller that pads 39-wide heads to 40 passes 39^-0.5 explicitly.                                                        */
+int pk_window_attn_fwd(const void* qkv, const float* rel_table, void* out, float* lse, int n_windows, int heads, int C,
+                       float softmax_scale, void* stream);
 int pk_window_attn_bwd_groups(int n_windows, int heads);
 int pk_window_attn_bwd_ws_floats(int n_windows, int heads);  /* size of dbias_partial in floats */
 /* fwd_out = the `out` tensor pk_window_attn_fwd produced for the same qkv (delta_i = sum_e dout[i][e] * out[i][e]). */
 int pk_window_attn_bwd(const void* qkv, const float* rel_table, const void* fwd_out, const void* dout, const float* lse, void* dqkv,
-                       float* dbias_partial, float* dtable, int n_windows, int heads, int C, void* stream);
+                       float* dbias_partial, float* dtable, int n_windows, int heads, int C, float softmax_scale, void* stream);
 
 /* ======================= normalisation / elementwise (HBM-bound, NHWC bf16, 16 bytes per lane) ==================== */
 int pk_sum_partials(const float* partial, int nb, int K, int stride, float* out, float scale, int accumulate, void* stream);

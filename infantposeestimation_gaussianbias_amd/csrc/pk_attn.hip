@@ -30,7 +30,8 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define AT_N 49
 #define AT_WS 7
-#define RP 40   // row pitch (bf16) of [64][32] row-major tiles
+// row pitch (bf16) of the [64][32*DK] row-major LDS tiles: 32*DK + 8 (40 for head_dim <= 32, 72 for head_dim <= 64)
+#define RPITCH(DK) (32 * (DK) + 8)
 
 __device__ __forceinline__ bf16x8 lds_frag(const uint16_t* base, int row, int pitch, int k0) {
     return *reinterpret_cast<const bf16x8*>(base + row * pitch + k0);
@@ -41,17 +42,17 @@ __device__ __forceinline__ bf16x8 lds_frag(const uint16_t* base, int row, int pi
 #define OOB_OFF 0x80000000u
 #define MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptr), 0, 0x7ffffff0, 0x00020000)
 // Row fragment straight from global memory: token row `row`, channels 8g .. 8g+7 (zeros outside the 49 x d slice).
-#define GLB_FRAG(rsrc, ld, d, row, g4) \
-    __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((row) < AT_N && (g4) * 8 < (d)) ? (unsigned)(((row) * (ld) + (g4) * 8) * 2) : OOB_OFF, 0, 0))
+#define GLB_FRAG(rsrc, ld, d, row, c0) \
+    __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((row) < AT_N && (c0) < (d)) ? (unsigned)(((row) * (ld) + (c0)) * 2) : OOB_OFF, 0, 0))
 // Fragment (row/column = channel col0 + l16, k = tokens in ACCUMULATOR ORDER for K-step s): slots jj = 0..3 are tokens
 // 32s + 4g + jj, slots 4..7 are tokens 32s + 16 + 4g + (jj-4), read from a row-major [64][RP] token tile.
-// ds_read_b64_tr_b16: within a 16-lane group lane i addresses 4 elements of row (i>>2) at columns 4(i&3).. and receives
+// `pitch` = RPITCH(DK).  ds_read_b64_tr_b16: within a 16-lane group lane i addresses 4 elements of row (i>>2) at columns 4(i&3).. and receives
 // column i of the 4 x 16 block.
-__device__ __forceinline__ bf16x8 tok_frag(const uint16_t* tile, int s, int col0, int lane) {
+__device__ __forceinline__ bf16x8 tok_frag(const uint16_t* tile, int pitch, int s, int col0, int lane) {
     const int g = lane >> 4, i = lane & 15;
-    const uint16_t* a0 = tile + (32 * s + 4 * g + (i >> 2)) * RP + col0 + 4 * (i & 3);
+    const uint16_t* a0 = tile + (32 * s + 4 * g + (i >> 2)) * pitch + col0 + 4 * (i & 3);
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * RP));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * pitch));
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 __device__ __forceinline__ int rel_a(int t) { return 13 * (t / AT_WS) + t % AT_WS; }   // rel_index(i,j) = rel_a(i) - rel_a(j) + 84
@@ -67,37 +68,43 @@ __device__ __forceinline__ void store4_bf16(uint16_t* dst, const f32x4 v, float 
     *reinterpret_cast<uint2*>(dst) = pk;
 }
 
-// Load a [49][d] slice (row stride ld) into a zero-padded [64][RP] row-major LDS tile (rows >= 49 and channels >= d are zero):
-// TILE_LOAD issues the four 16-byte loads of this lane, TILE_STORE writes them to LDS (call after all loads are issued).
-#define TILE_LOAD(v, rsrc, ld, d, lane)                                                                              \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_) {                                                               \
-        const int row_ = ((lane) >> 2) + 16 * k_, ch_ = (lane) & 3;                                                   \
+// Load a [49][d] slice (row stride ld) into a zero-padded [64][RPITCH(DK)] row-major LDS tile (rows >= 49 and channels >= d
+// are zero): TILE_LOAD issues this lane's 4*DK 16-byte loads, TILE_STORE writes them to LDS (call after all loads are issued).
+#define TILE_LOAD(v, rsrc, ld, d, lane, DK)                                                                          \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4 * (DK); ++k_) {                                                        \
+        const int idx_ = (lane) + 64 * k_, row_ = idx_ / (4 * (DK)), ch_ = idx_ % (4 * (DK));                         \
         v[k_] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (row_ < AT_N && ch_ * 8 < (d)) ? (unsigned)((row_ * (ld) + ch_ * 8) * 2) : OOB_OFF, 0, 0); \
     }
-#define TILE_STORE(v, tile, lane)                                                                                    \
-    _Pragma("unroll") for (int k_ = 0; k_ < 4; ++k_)                                                                 \
-        *reinterpret_cast<u32x4*>((tile) + (((lane) >> 2) + 16 * k_) * RP + ((lane) & 3) * 8) = v[k_];
+#define TILE_STORE(v, tile, lane, DK)                                                                                \
+    _Pragma("unroll") for (int k_ = 0; k_ < 4 * (DK); ++k_) {                                                        \
+        const int idx_ = (lane) + 64 * k_, row_ = idx_ / (4 * (DK)), ch_ = idx_ % (4 * (DK));                         \
+        *reinterpret_cast<u32x4*>((tile) + row_ * RPITCH(DK) + ch_ * 8) = v[k_];                                      \
+    }
 
 // ================================================================================================ forward
+template <int DK, int NCE>   // DK: 32-channel K-steps of the head dimension (1: d <= 32, 2: d <= 64); NCE = ceil(d / 16)
 __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict__ qkv, const float* __restrict__ table,
                                                      uint16_t* __restrict__ out, float* __restrict__ lse, int heads, int C, int d,
                                                      float scale) {
+    constexpr int RP = RPITCH(DK);
     __shared__ __attribute__((aligned(16))) uint16_t sV[64 * RP];
     __shared__ float sBias[176];
     const int lane = threadIdx.x, g4 = lane >> 4, l16 = lane & 15;
     const int w = blockIdx.x / heads, h = blockIdx.x - w * heads;
     const uint16_t* base = qkv + (size_t)w * AT_N * 3 * C + h * d;
     const auto rq = MAKE_RSRC(base), rk = MAKE_RSRC(base + C), rv = MAKE_RSRC(base + 2 * C);
-    u32x4 tv[4];
-    TILE_LOAD(tv, rv, 3 * C, d, lane);
-    bf16x8 qf[4], kf[4];
+    u32x4 tv[4 * DK];
+    TILE_LOAD(tv, rv, 3 * C, d, lane, DK);
+    bf16x8 qf[4][DK], kf[4][DK];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-        qf[t] = GLB_FRAG(rq, 3 * C, d, 16 * t + l16, g4);
-        kf[t] = GLB_FRAG(rk, 3 * C, d, 16 * t + l16, g4);
-    }
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int ks = 0; ks < DK; ++ks) {
+            qf[t][ks] = GLB_FRAG(rq, 3 * C, d, 16 * t + l16, 32 * ks + 8 * g4);
+            kf[t][ks] = GLB_FRAG(rk, 3 * C, d, 16 * t + l16, 32 * ks + 8 * g4);
+        }
     for (int i = lane; i < 169; i += 64) sBias[i] = table[i * heads + h];
-    TILE_STORE(tv, sV, lane);
+    TILE_STORE(tv, sV, lane, DK);
     int aj[4][4];                       // 84 - A(j) for this lane's 16 keys j = 16cj + 4g4 + r (-1: tile padding)
 #pragma unroll
     for (int cj = 0; cj < 4; ++cj)
@@ -107,11 +114,11 @@ __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict_
             aj[cj][r] = j < AT_N ? 84 - rel_a(j) : -1;
         }
     __syncthreads();
-    bf16x8 vt[2][2];                    // V^T fragments [K-step][channel tile]
+    bf16x8 vt[2][NCE];                  // V^T fragments [token K-step][channel tile]
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int ce = 0; ce < 2; ++ce) vt[s][ce] = tok_frag(sV, s, 16 * ce, lane);
+        for (int ce = 0; ce < NCE; ++ce) vt[s][ce] = tok_frag(sV, RP, s, 16 * ce, lane);
 
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -120,7 +127,11 @@ __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict_
         const int ai = rel_a(i < AT_N ? i : 0);
         f32x4 st[4];
 #pragma unroll
-        for (int cj = 0; cj < 4; ++cj) st[cj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cj], qf[ci], zero, 0, 0, 0);
+        for (int cj = 0; cj < 4; ++cj) {
+            st[cj] = zero;
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) st[cj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[cj][ks], qf[ci][ks], st[cj], 0, 0, 0);
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj)
@@ -146,8 +157,7 @@ __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict_
         if (g4 == 0 && i < AT_N && lse) lse[((size_t)w * heads + h) * AT_N + i] = mx + __logf(sum);
         const bf16x8 p0 = pack_frag(st[0], st[1], inv), p1 = pack_frag(st[2], st[3], inv);
 #pragma unroll
-        for (int ce = 0; ce < 2; ++ce) {
-            if (ce * 16 >= d) break;
+        for (int ce = 0; ce < NCE; ++ce) {
             f32x4 o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[0][ce], p0, zero, 0, 0, 0);
             o = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vt[1][ce], p1, o, 0, 0, 0);
             const int e = 16 * ce + 4 * g4;          // this lane: channels e..e+3 of token i
@@ -156,15 +166,28 @@ __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict_
     }
 }
 
+// head_dim d (multiple of 8, <= 64) -> kernel instantiation <DK, NCE>
+#define ATTN_DISPATCH(d, LAUNCH)            \
+    do {                                    \
+        if ((d) <= 16) { LAUNCH(1, 1); }    \
+        else if ((d) <= 32) { LAUNCH(1, 2); } \
+        else if ((d) <= 48) { LAUNCH(2, 3); } \
+        else { LAUNCH(2, 4); }              \
+    } while (0)
+
 extern "C" int pk_window_attn_fwd(const void* qkv, const float* rel_table, void* out, float* lse, int n_windows, int heads, int C,
-                                  void* stream) {
+                                  float softmax_scale, void* stream) {
     PK_REQUIRE(qkv && rel_table && out && n_windows > 0 && heads > 0 && C > 0, "pk_window_attn_fwd: bad argument");
     PK_REQUIRE(C % heads == 0, "pk_window_attn_fwd: C=%d not divisible by heads=%d", C, heads);
     const int d = C / heads;
-    PK_SUPPORTED(d <= 32 && (d & 7) == 0, "pk_window_attn_fwd: head_dim %d (supported: multiples of 8 up to 32)", d);
+    PK_SUPPORTED(d <= 64 && (d & 7) == 0, "pk_window_attn_fwd: head_dim %d (supported: multiples of 8 up to 64)", d);
     PK_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)out)) & 15) == 0 && (C & 7) == 0, "pk_window_attn_fwd: alignment");
-    hipLaunchKernelGGL(k_win_attn_fwd, dim3(n_windows * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv, rel_table,
-                       (uint16_t*)out, lse, heads, C, d, 1.f / sqrtf((float)d));
+    const float scale = softmax_scale > 0.f ? softmax_scale : 1.f / sqrtf((float)d);
+#define LAUNCH_FWD(DK_, NCE_)                                                                                                          \
+    hipLaunchKernelGGL((k_win_attn_fwd<DK_, NCE_>), dim3(n_windows * heads), dim3(64), 0, (hipStream_t)stream, (const uint16_t*)qkv, \
+                       rel_table, (uint16_t*)out, lse, heads, C, d, scale)
+    ATTN_DISPATCH(d, LAUNCH_FWD);
+#undef LAUNCH_FWD
     return pk_launch_status("pk_window_attn_fwd");
 }
 
@@ -175,12 +198,13 @@ extern "C" int pk_window_attn_fwd(const void* qkv, const float* rel_table, void*
 // quantity depends on a whole score row any more: both passes decompose into independent 32-key (pass 1) / 32-query
 // (pass 2) chunks of two accumulator tiles, which keeps ~130 registers live instead of > 256 and lets three waves share a
 // SIMD.  P is recomputed from the saved log-sum-exp in each layout.
-template <int NCE>   // 16-channel tiles of the head dimension (1: d <= 16, 2: d <= 32)
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_win_attn_bwd(const uint16_t* __restrict__ qkv, const float* __restrict__ table,
+template <int DK, int NCE>   // as in the forward kernel
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1 ? 2 : 1, DK == 1 ? 2 : 1))) k_win_attn_bwd(const uint16_t* __restrict__ qkv, const float* __restrict__ table,
                                                      const uint16_t* __restrict__ fwd_out, const uint16_t* __restrict__ dout,
                                                      const float* __restrict__ lse, uint16_t* __restrict__ dqkv,
                                                      float* __restrict__ dbias_part, int n_windows, int heads, int C, int d, float scale,
                                                      int wstride) {
+    constexpr int RP = RPITCH(DK);
     __shared__ __attribute__((aligned(16))) uint16_t sTiles[3 * 64 * RP];      // Q, K, dO tiles; reused for the bias-gradient fold
     __shared__ __attribute__((aligned(16))) float sLse[64], sDelta[64];
     __shared__ float sBias[176];
@@ -209,27 +233,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         const uint16_t* dob = dout + (size_t)w * AT_N * C + h * d;
         const auto rq = MAKE_RSRC(base), rk = MAKE_RSRC(base + C), rv = MAKE_RSRC(base + 2 * C), rg = MAKE_RSRC(dob);
         const auto ro = MAKE_RSRC(fwd_out + (size_t)w * AT_N * C + h * d);
-        u32x4 tq[4], tk[4], tg[4], orow[4], grow[4];
-        TILE_LOAD(tq, rq, 3 * C, d, lane0);
-        TILE_LOAD(tk, rk, 3 * C, d, lane0);
-        TILE_LOAD(tg, rg, C, d, lane0);
-        bf16x8 vf[4];                   // V row fragments (token rows, k = channel) straight from global
+        u32x4 tq[4 * DK], tk[4 * DK], tg[4 * DK], orow[4 * DK], grow[4 * DK];
+        TILE_LOAD(tq, rq, 3 * C, d, lane0, DK);
+        TILE_LOAD(tk, rk, 3 * C, d, lane0, DK);
+        TILE_LOAD(tg, rg, C, d, lane0, DK);
+        bf16x8 vf[4][DK];               // V row fragments (token rows, k = channel) straight from global
 #pragma unroll
-        for (int t = 0; t < 4; ++t) vf[t] = GLB_FRAG(rv, 3 * C, d, 16 * t + (lane0 & 15), lane0 >> 4);
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {   // token `lane0`: its rows of O and dO for delta = sum_e dO*O
+            for (int ks = 0; ks < DK; ++ks) vf[t][ks] = GLB_FRAG(rv, 3 * C, d, 16 * t + (lane0 & 15), 32 * ks + 8 * (lane0 >> 4));
+#pragma unroll
+        for (int c = 0; c < 4 * DK; ++c) {   // token `lane0`: its rows of O and dO for delta = sum_e dO*O
             const unsigned off = (lane0 < AT_N && c * 8 < d) ? (unsigned)((lane0 * C + c * 8) * 2) : OOB_OFF;
             orow[c] = __builtin_amdgcn_raw_buffer_load_b128(ro, off, 0, 0);
             grow[c] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
         }
         const float l = lane0 < AT_N ? lse[((size_t)w * heads + h) * AT_N + lane0] : 0.f;
-        TILE_STORE(tq, sQ, lane0);
-        TILE_STORE(tk, sK, lane0);
-        TILE_STORE(tg, sdO, lane0);
+        TILE_STORE(tq, sQ, lane0, DK);
+        TILE_STORE(tk, sK, lane0, DK);
+        TILE_STORE(tg, sdO, lane0, DK);
         {
             float de = 0.f;
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
+            for (int c = 0; c < 4 * DK; ++c)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     de += __uint_as_float(orow[c][q] << 16) * __uint_as_float(grow[c][q] << 16);
@@ -254,16 +280,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const bool iok = i < AT_N;
             const int ai = rel_a(iok ? i : 0) + 84 + lz;
             const float li = sLse[i], di = sDelta[i];
-            const bf16x8 qfi = lds_frag(sQ, i, RP, g4 * 8), ofi = lds_frag(sdO, i, RP, g4 * 8);
-            f32x4 acc[2] = {zero, zero};
+            bf16x8 qfi[DK], ofi[DK];
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) {
+                qfi[ks] = lds_frag(sQ, i, RP, 32 * ks + g4 * 8);
+                ofi[ks] = lds_frag(sdO, i, RP, 32 * ks + g4 * 8);
+            }
+            f32x4 acc[NCE];
+#pragma unroll
+            for (int ce = 0; ce < NCE; ++ce) acc[ce] = zero;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 f32x4 ds[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int cj = 2 * s + u;
-                    const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sK, 16 * cj + l16, RP, g4 * 8), qfi, zero, 0, 0, 0);
-                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cj], ofi, zero, 0, 0, 0);
+                    f32x4 sc = zero, dp = zero;
+#pragma unroll
+                    for (int ks = 0; ks < DK; ++ks) {
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sK, 16 * cj + l16, RP, 32 * ks + g4 * 8), qfi[ks], sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[cj][ks], ofi[ks], dp, 0, 0, 0);
+                    }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         const float ev = __expf(sc[r] * scale + sBias[ai - (a4[cj][r] >= 0 ? a4[cj][r] : 0)] - li);
@@ -275,7 +312,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const bf16x8 df = pack_frag(ds[0], ds[1], 1.f);
 #pragma unroll
                 for (int ce = 0; ce < NCE; ++ce)
-                    acc[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sK, s, 16 * ce, lane), df, acc[ce], 0, 0, 0);
+                    acc[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sK, RP, s, 16 * ce, lane), df, acc[ce], 0, 0, 0);
             }
 #pragma unroll
             for (int ce = 0; ce < NCE; ++ce) {
@@ -290,16 +327,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
             const int j = 16 * cj + l16;
             const bool jok = j < AT_N;
             const int ajn = 84 - rel_a(jok ? j : 0) + lz;
-            const bf16x8 kfj = lds_frag(sK, j, RP, g4 * 8);
-            f32x4 dv[2] = {zero, zero}, dk[2] = {zero, zero};
+            bf16x8 kfj[DK];
+#pragma unroll
+            for (int ks = 0; ks < DK; ++ks) kfj[ks] = lds_frag(sK, j, RP, 32 * ks + g4 * 8);
+            f32x4 dv[NCE], dk[NCE];
+#pragma unroll
+            for (int ce = 0; ce < NCE; ++ce) dv[ce] = dk[ce] = zero;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 f32x4 pp[2], ds[2];
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int ci = 2 * s + u;
-                    const f32x4 sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sQ, 16 * ci + l16, RP, g4 * 8), kfj, zero, 0, 0, 0);
-                    const f32x4 dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sdO, 16 * ci + l16, RP, g4 * 8), vf[cj], zero, 0, 0, 0);
+                    f32x4 sc = zero, dp = zero;
+#pragma unroll
+                    for (int ks = 0; ks < DK; ++ks) {
+                        sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sQ, 16 * ci + l16, RP, 32 * ks + g4 * 8), kfj[ks], sc, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sdO, 16 * ci + l16, RP, 32 * ks + g4 * 8), vf[cj][ks], dp, 0, 0, 0);
+                    }
                     const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sLse[16 * ci + 4 * g4]);
                     const f32x4 de4 = *reinterpret_cast<const f32x4*>(&sDelta[16 * ci + 4 * g4]);
 #pragma unroll
@@ -313,8 +358,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
                 const bf16x8 pf = pack_frag(pp[0], pp[1], 1.f), df = pack_frag(ds[0], ds[1], 1.f);
 #pragma unroll
                 for (int ce = 0; ce < NCE; ++ce) {
-                    dv[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sdO, s, 16 * ce, lane), pf, dv[ce], 0, 0, 0);
-                    dk[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sQ, s, 16 * ce, lane), df, dk[ce], 0, 0, 0);
+                    dv[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sdO, RP, s, 16 * ce, lane), pf, dv[ce], 0, 0, 0);
+                    dk[ce] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(tok_frag(sQ, RP, s, 16 * ce, lane), df, dk[ce], 0, 0, 0);
                 }
             }
 #pragma unroll
@@ -330,7 +375,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     // Fold the register-resident [49][49] bias gradient onto the 169 table entries inside the workgroup (fixed summation
     // order -> deterministic): the partial result per workgroup is 169 floats instead of 2401.
     __syncthreads();
-    float* sD = reinterpret_cast<float*>(sTiles);            // 49*49*4 = 9604 B <= 15360 B
+    float* sD = reinterpret_cast<float*>(sTiles);            // 49*49*4 = 9604 B <= 3*64*RP*2 = 15360 B
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -386,23 +431,23 @@ extern "C" int pk_window_attn_bwd_groups(int n_windows, int heads) {
 }
 extern "C" int pk_window_attn_bwd_ws_floats(int n_windows, int heads) { return pk_window_attn_bwd_groups(n_windows, heads) * 169; }
 extern "C" int pk_window_attn_bwd(const void* qkv, const float* rel_table, const void* fwd_out, const void* dout, const float* lse,
-                                  void* dqkv, float* dbias_partial, float* dtable, int n_windows, int heads, int C, void* stream) {
+                                  void* dqkv, float* dbias_partial, float* dtable, int n_windows, int heads, int C, float softmax_scale,
+                                  void* stream) {
     PK_REQUIRE(qkv && rel_table && fwd_out && dout && lse && dqkv && dbias_partial && dtable, "pk_window_attn_bwd: null pointer");
     PK_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)fwd_out) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) == 0 && (C & 7) == 0,
                "pk_window_attn_bwd: alignment");
     PK_REQUIRE(n_windows > 0 && heads > 0 && C > 0 && C % heads == 0, "pk_window_attn_bwd: bad sizes");
     const int d = C / heads;
-    PK_SUPPORTED(d <= 32 && (d & 7) == 0, "pk_window_attn_bwd: head_dim %d", d);
+    PK_SUPPORTED(d <= 64 && (d & 7) == 0, "pk_window_attn_bwd: head_dim %d (supported: multiples of 8 up to 64)", d);
+    const float scale = softmax_scale > 0.f ? softmax_scale : 1.f / sqrtf((float)d);
     const int groups = pk_window_attn_bwd_groups(n_windows, heads);
     hipStream_t st = (hipStream_t)stream;
-    if (d > 16)
-        hipLaunchKernelGGL(k_win_attn_bwd<2>, dim3(groups), dim3(64), 0, st, (const uint16_t*)qkv, rel_table, (const uint16_t*)fwd_out,
-                           (const uint16_t*)dout, lse, (uint16_t*)dqkv, dbias_partial, n_windows, heads, C, d, 1.f / sqrtf((float)d),
-                           groups / heads);
-    else
-        hipLaunchKernelGGL(k_win_attn_bwd<1>, dim3(groups), dim3(64), 0, st, (const uint16_t*)qkv, rel_table, (const uint16_t*)fwd_out,
-                           (const uint16_t*)dout, lse, (uint16_t*)dqkv, dbias_partial, n_windows, heads, C, d, 1.f / sqrtf((float)d),
-                           groups / heads);
+#define LAUNCH_BWD(DK_, NCE_)                                                                                                     \
+    hipLaunchKernelGGL((k_win_attn_bwd<DK_, NCE_>), dim3(groups), dim3(64), 0, st, (const uint16_t*)qkv, rel_table,              \
+                       (const uint16_t*)fwd_out, (const uint16_t*)dout, lse, (uint16_t*)dqkv, dbias_partial, n_windows, heads, C, d, \
+                       scale, groups / heads)
+    ATTN_DISPATCH(d, LAUNCH_BWD);
+#undef LAUNCH_BWD
     hipLaunchKernelGGL(k_relbias_reduce, dim3(169, heads), dim3(256), 0, st, dbias_partial, groups, heads, dtable);
     return pk_launch_status("pk_window_attn_bwd");
 }

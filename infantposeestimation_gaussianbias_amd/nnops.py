@@ -395,7 +395,7 @@ class _AttnHalf(torch.autograd.Function):
         qkv = _linear(u, wc.fwd[id(wqkv)], Mw, 3 * C, C, bias=bqkv, a_map=amap)
         o = _e((Mw, C), BF16, x.device)
         lse = _e((B * nwin * heads * WS * WS,), F32, x.device)
-        call("pk_window_attn_fwd", qkv, table, o, lse, B * nwin, heads, C, stream_ptr())
+        call("pk_window_attn_fwd", qkv, table, o, lse, B * nwin, heads, C, 0.0, stream_ptr())
         s1 = None if scale1 is None else scale1.float().contiguous()
         y = _linear(o, wc.fwd[id(wproj)], M, C, C, bias=bproj, residual=x2, res_scale=s1, o_map=amap, M=Mw, rps=H * W)
         ctx.save_for_backward(x2, u, mean, rstd, qkv, o, lse, g1, table, s1 if s1 is not None else x.new_empty(0),
@@ -422,7 +422,7 @@ class _AttnHalf(torch.autograd.Function):
         dqkv = _e((Mw, 3 * C), BF16, dev)
         part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads),), F32, dev)
         dtable, s_t = _sink(ptab)
-        call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, stream_ptr())
+        call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, 0.0, stream_ptr())
         # qkv linear: scatter the token gradients back to pixel rows (pad tokens dropped)
         du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
         dst, s_wq = _sink(pwqkv)

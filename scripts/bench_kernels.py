@@ -103,13 +103,13 @@ def attn_cases(flt):
         o = torch.empty(nw * 49, C, device=DEV, dtype=BF)
         lse = torch.empty(nw * heads * 49, device=DEV)
         flops = 4.0 * nw * heads * 49 * 49 * (C // heads)
-        sec = timeit(lambda: call("pk_window_attn_fwd", qkv, table, o, lse, nw, heads, C, stream_ptr()))
+        sec = timeit(lambda: call("pk_window_attn_fwd", qkv, table, o, lse, nw, heads, C, 0.0, stream_ptr()))
         report(name + " fwd", sec, flops, (qkv.numel() + o.numel()) * 2)
         go = torch.randn(nw * 49, C, device=DEV).to(BF)
         dqkv = torch.empty_like(qkv)
         part = torch.empty(lib.pk_window_attn_bwd_ws_floats(nw, heads), device=DEV)
         dt = torch.empty(169, heads, device=DEV)
-        sec = timeit(lambda: call("pk_window_attn_bwd", qkv, table, o, go, lse, dqkv, part, dt, nw, heads, C, stream_ptr()))
+        sec = timeit(lambda: call("pk_window_attn_bwd", qkv, table, o, go, lse, dqkv, part, dt, nw, heads, C, 0.0, stream_ptr()))
         report(name + " bwd", sec, 2.5 * flops, (2 * qkv.numel() + go.numel()) * 2)
 
 

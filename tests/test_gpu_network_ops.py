@@ -243,7 +243,8 @@ def test_linear_rowmaps_gelu_residual(N):
 
 
 # ------------------------------------------------------------------------------------------------ attention core
-@pytest.mark.parametrize("heads,Cc,nw", [(1, 32, 5), (2, 64, 3), (4, 128, 2), (8, 256, 300), (2, 32, 4)])
+@pytest.mark.parametrize("heads,Cc,nw", [(1, 32, 5), (2, 64, 3), (4, 128, 2), (8, 256, 300), (2, 32, 4), (4, 32, 3),
+                                         (2, 80, 3), (1, 48, 2), (2, 128, 2), (3, 168, 70)])
 def test_window_attention_core(N, heads, Cc, nw):
     from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
     d = Cc // heads
@@ -260,16 +261,49 @@ def test_window_attention_core(N, heads, Cc, nw):
     ref.backward(go)
     o = torch.empty(nw * 49, Cc, device=DEV, dtype=BF)
     lse = torch.empty(nw * heads * 49, device=DEV)
-    call("pk_window_attn_fwd", qkv.to(DEV, BF), table.to(DEV), o, lse, nw, heads, Cc, stream_ptr())
+    call("pk_window_attn_fwd", qkv.to(DEV, BF), table.to(DEV), o, lse, nw, heads, Cc, 0.0, stream_ptr())
     assert err(C(o), ref.detach()) < 1e-2                      # P is rounded to bf16 before the PV product
     ref_lse = torch.logsumexp(logits.detach(), -1)            # (nw, heads, 49)
     assert err(C(lse).reshape(nw, heads, 49), ref_lse) < 1e-4
     dqkv = torch.empty(nw * 49, 3 * Cc, device=DEV, dtype=BF)
     part = torch.empty(lib.pk_window_attn_bwd_ws_floats(nw, heads), device=DEV)
     dtab = torch.empty(169, heads, device=DEV)
-    call("pk_window_attn_bwd", qkv.to(DEV, BF), table.to(DEV), o, go.to(DEV, BF), lse, dqkv, part, dtab, nw, heads, Cc, stream_ptr())
+    call("pk_window_attn_bwd", qkv.to(DEV, BF), table.to(DEV), o, go.to(DEV, BF), lse, dqkv, part, dtab, nw, heads, Cc, 0.0, stream_ptr())
     assert err(C(dqkv), qr.grad) < 2e-2
     assert err(C(dtab), tr.grad) < 2e-2
+
+
+def test_window_attention_padded_heads_explicit_scale(N):
+    """HRFormer-base layout: 39-wide heads stored in 40-wide slots (slot 39 zero) with softmax scale 39^-0.5 passed explicitly
+    must equal the reference attention on the real 39-wide heads (hrformer.py:140,183)."""
+    from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
+    heads, dr, dp, nw = 2, 39, 40, 4
+    real = rnd(nw * 49, 3, heads, dr, seed=11)
+    table = torch.randn(169, heads, generator=torch.Generator().manual_seed(12)) * 0.5
+    ys, xs = torch.meshgrid(torch.arange(7), torch.arange(7), indexing="ij")
+    ys, xs = ys.reshape(-1), xs.reshape(-1)
+    idx = (ys[:, None] - ys[None, :] + 6) * 13 + (xs[:, None] - xs[None, :] + 6)
+    qr = real.clone().requires_grad_(True)
+    t = qr.reshape(nw, 49, 3, heads, dr)
+    logits = torch.einsum("bnhd,bmhd->bhnm", t[:, :, 0] * dr ** -0.5, t[:, :, 1]) + table[idx.reshape(-1)].reshape(49, 49, heads).permute(2, 0, 1)[None]
+    ref = torch.einsum("bhnm,bmhd->bnhd", torch.softmax(logits, -1), t[:, :, 2])          # (nw, 49, heads, 39)
+    go = rnd(nw, 49, heads, dr, seed=13)
+    ref.backward(go)
+    pad = lambda a: F.pad(a, (0, dp - dr))
+    qkv_p = pad(real).reshape(nw * 49, 3 * heads * dp).to(DEV, BF)
+    go_p = pad(go).reshape(nw * 49, heads * dp).to(DEV, BF)
+    Cp = heads * dp
+    o = torch.empty(nw * 49, Cp, device=DEV, dtype=BF)
+    lse = torch.empty(nw * heads * 49, device=DEV)
+    call("pk_window_attn_fwd", qkv_p, table.to(DEV), o, lse, nw, heads, Cp, dr ** -0.5, stream_ptr())
+    o_c = C(o).reshape(nw, 49, heads, dp)
+    assert err(o_c[..., :dr], ref.detach()) < 1e-2 and float(o_c[..., dr:].abs().max()) == 0.0
+    dqkv = torch.empty(nw * 49, 3 * Cp, device=DEV, dtype=BF)
+    part = torch.empty(lib.pk_window_attn_bwd_ws_floats(nw, heads), device=DEV)
+    dtab = torch.empty(169, heads, device=DEV)
+    call("pk_window_attn_bwd", qkv_p, table.to(DEV), o, go_p, lse, dqkv, part, dtab, nw, heads, Cp, dr ** -0.5, stream_ptr())
+    dq_c = C(dqkv).reshape(nw * 49, 3, heads, dp)
+    assert err(dq_c[..., :dr], qr.grad) < 2e-2 and float(dq_c[..., dr:].abs().max()) == 0.0
 
 
 # ------------------------------------------------------------------------------------------------ whole HRFormer block

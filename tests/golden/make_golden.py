@@ -525,6 +525,53 @@ def cap_models():
     return meta
 
 
+def cap_base():
+    """HRFormer-base + fusion head, K=13 (BASELINE cfg 5 at reduced resolution): C=(78,156,312,624), head_dim 39 -- the
+    configuration whose channel counts are not multiples of 8 (exercises the padded-twin path of the build)."""
+    import models
+    out, meta = {}, {}
+    pairs = [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12)]
+    m = models.PoseEstimator("hrformer_base", 13, False, "fusion", True)
+    load_recipe(m, salt=44)
+    m.eval()
+    x = T(synth_input("base_eval", (1, 3, 128, 96)))
+    with torch.no_grad():
+        o = m(x)
+        kp, sc = m.inference(x, flip=True, flip_pairs=pairs)
+        kp0, sc0 = m.inference(x, flip=False)
+    out["base_eval_hm"], out["base_eval_fw"] = N(o["heatmaps"]), N(o["fusion_weight"])
+    out["base_eval_off"], out["base_eval_var"] = N(o["offsets"])[:, :, :, ::4, ::4], N(o["variances"])[:, :, ::4, ::4]
+    out["base_eval_flip_kp"], out["base_eval_flip_sc"], out["base_eval_kp"], out["base_eval_sc"] = N(kp), N(sc), N(kp0), N(sc0)
+    # train-mode step (DropPath off), B=2 at 128x96
+    load_recipe(m, salt=44)
+    m.train()
+    for mod in m.modules():
+        if mod.__class__.__name__ == "DropPath":
+            mod.drop_prob = 0.0
+    B, K, H, W, win, hin = 2, 13, 32, 24, 96, 128
+    hm, off, var, tgt, w, gt = synth_loss_inputs("base_train", B, K, H, W, win, hin, True)
+    x = T(synth_input("base_train", (B, 3, hin, win)))
+    o = m(x, T(tgt), T(w), T(gt), input_size=(win, hin))
+    m.zero_grad(set_to_none=True)
+    o["loss"].backward()
+    names = ["heatmap_loss", "offset_loss", "peak_loss", "variance_loss", "overlap_loss", "shape_loss", "total_loss"]
+    out["base_train_losses"] = np.array([float(o["losses"][n]) for n in names])
+    out["base_train_tgt"], out["base_train_w"], out["base_train_gt"] = tgt, w, gt
+    out["base_train_hm"] = N(o["heatmaps"])
+    gn = {k: float(p.grad.norm()) if p.grad is not None else -1.0 for k, p in m.named_parameters()}
+    meta["base_train_gradnorm"] = gn
+    meta["base_train_nograd"] = [k for k, v in gn.items() if v < 0]
+    sd = dict(m.named_parameters())
+    for k in ("backbone.stage2.0.branches.0.0.attn.qkv.weight", "backbone.stage2.0.branches.0.0.attn.proj.weight",
+              "backbone.stage3.1.branches.1.0.attn.relative_position_bias_table", "backbone.stage4.0.branches.3.1.norm2.weight",
+              "backbone.stage2.0.branches.1.0.mlp.fc1.weight", "backbone.transition1.0.0.weight", "head.shared_layers.0.weight"):
+        out["base_train_g." + k] = N(sd[k].grad)
+    for k in ("backbone.bn1.running_var", "backbone.stage3.0.fuse_layers.0.1.1.running_mean"):
+        out["base_train_buf." + k] = N(dict(m.named_buffers())[k])
+    save("model_base.npz", **out)
+    return meta
+
+
 # ----------------------------------------------------------------------------- S1
 def cap_schedule():
     import train as rt  # reference train.py (tensorboard mocked)
@@ -549,6 +596,14 @@ def cap_schedule():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "base":       # add the HRFormer-base fixtures without touching the others
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        meta["base"] = cap_base()
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, separators=(",", ":"))
+        print("done (base)")
+        return
     meta = {}
     print("capturing golden vectors from", REF)
     cap_t1()
@@ -559,6 +614,7 @@ def main():
     cap_decode()
     meta["models"] = cap_models()
     meta["schedule"] = cap_schedule()
+    meta["base"] = cap_base()
     meta["torch"] = torch.__version__
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, separators=(",", ":"))

@@ -165,12 +165,15 @@ int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* s
               const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
               int64_t rows, int C, int relu, void* stream);
 int pk_relu_bwd(const void* dy, const void* y, void* dx, int64_t numel, void* stream);
-/* nn.LayerNorm(C, eps 1e-5) over the channel dim of NHWC rows (hrformer.py:240,252,273,288) */
+/* nn.LayerNorm(C, eps 1e-5) over the channel dim of NHWC rows (hrformer.py:240,252,273,288).  C = row width (multiple of 8,
+ * <= 1024); C_real (0 = C) = number of real channels when the rows carry zero padding: statistics over the real channels,
+ * padded outputs / input gradients are zero, gamma/beta are read for the real channels only.                             */
 int pk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
-                     int64_t rows, int C, float eps, void* stream);
+                     int64_t rows, int C, int C_real, float eps, void* stream);
 int pk_ln_bwd_blocks(int64_t rows);                          /* partial needs blocks*2*C floats */
 int pk_layernorm_bwd(const void* dy, const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
-                     const void* dresidual, void* dx, float* partial, float* dgamma, float* dbeta, int64_t rows, int C, void* stream);
+                     const void* dresidual, void* dx, float* partial, float* dgamma, float* dbeta, int64_t rows, int C, int C_real,
+                     void* stream);
 int pk_colsum_bf16(const void* g, const int32_t* rowmap, const float* row_scale, int rows_per_sample, float* partial,
                    float* out, int64_t rows, int N, void* stream);
 /* exchange unit sum (hrformer.py:471-489 == hrnet.py:207-225): out = relu?(sum_i bilinear_up_i(x_i)), F.interpolate

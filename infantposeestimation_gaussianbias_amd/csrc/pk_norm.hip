@@ -266,140 +266,190 @@ extern "C" int pk_relu_bwd(const void* dy, const void* y, void* dx, int64_t nume
 }
 
 // ================================================================================================ LayerNorm
-// Row of C channels handled by L = pow2 >= C/8 lanes (8 channels per lane); 64/L rows per wave.
-template <int L>
+// Row of C channels handled by L = pow2 >= C/(8*CPL) lanes, CPL chunks of 8 channels per lane (CPL = 2 only for C > 512);
+// 64/L rows per wave.  `Cr` (<= C) is the number of REAL channels: statistics are taken over the first Cr channels only
+// (the padded twin of HRFormer-base keeps 78 real channels in 80-wide rows; padded inputs are zero, padded outputs are
+// forced to zero) -- Cr == C for every natively supported model.
+template <int L, int CPL>
 __global__ void __launch_bounds__(256) k_ln_fwd(const uint4* __restrict__ x, const float* __restrict__ gamma,
                                                 const float* __restrict__ beta, uint4* __restrict__ y, float* __restrict__ mean_out,
-                                                float* __restrict__ rstd_out, int64_t rows, int C, float eps) {
+                                                float* __restrict__ rstd_out, int64_t rows, int C, int Cr, float eps) {
     const int cchunks = C / 8, sub = threadIdx.x % L;
     const int64_t row = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) / L;
-    const bool on = row < rows && sub < cchunks;
-    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (on) unpack8(x[(size_t)row * cchunks + sub], v);
+    float v[CPL][8];
+    bool on[CPL];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = sub + c * L;
+        on[c] = row < rows && ch < cchunks;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[c][j] = 0.f;
+        if (on[c]) unpack8(x[(size_t)row * cchunks + ch], v[c]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s += (ch * 8 + j < Cr) ? v[c][j] : 0.f;
+    }
 #pragma unroll
     for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o, 64);
-    const float mean = s / (float)C;
+    const float mean = s / (float)Cr;
     float q = 0.f;
-    if (on) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) q += (v[j] - mean) * (v[j] - mean);
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = sub + c * L;
+        if (on[c]) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) q += (ch * 8 + j < Cr) ? (v[c][j] - mean) * (v[c][j] - mean) : 0.f;
+        }
     }
 #pragma unroll
     for (int o = 1; o < L; o <<= 1) q += __shfl_xor(q, o, 64);
-    const float rstd = rsqrtf(q / (float)C + eps);
-    if (!on) return;
+    const float rstd = rsqrtf(q / (float)Cr + eps);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = (v[j] - mean) * rstd * gamma[sub * 8 + j] + beta[sub * 8 + j];
-    y[(size_t)row * cchunks + sub] = pack8(v);
-    if (sub == 0) {
+    for (int c = 0; c < CPL; ++c) {
+        const int ch = sub + c * L;
+        if (!on[c]) continue;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            v[c][j] = (ch * 8 + j < Cr) ? (v[c][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j] : 0.f;
+        y[(size_t)row * cchunks + ch] = pack8(v[c]);
+    }
+    if (sub == 0 && row < rows) {
         mean_out[row] = mean;
         rstd_out[row] = rstd;
     }
 }
-#define LN_DISPATCH(KERNEL, L, ...)                                                                                     \
+#define LN_DISPATCH(KERNEL, L, CPL, ...)                                                                                \
     do {                                                                                                                \
         const int64_t threads = rows * (L);                                                                             \
-        hipLaunchKernelGGL((KERNEL<L>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, __VA_ARGS__);        \
+        hipLaunchKernelGGL((KERNEL<L, CPL>), dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, __VA_ARGS__);   \
     } while (0)
 static int ln_lanes(int C) {
     int l = 1;
-    while (l * 8 < C) l <<= 1;
+    while (l * 8 < C && l < 64) l <<= 1;
     return l;
 }
 extern "C" int pk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
-                                int64_t rows, int C, float eps, void* stream) {
+                                int64_t rows, int C, int C_real, float eps, void* stream) {
     PK_REQUIRE(x && gamma && beta && y && save_mean && save_rstd && rows > 0, "pk_layernorm_fwd: bad argument");
-    PK_SUPPORTED(C >= 8 && (C & 7) == 0 && C <= 512, "pk_layernorm_fwd: C=%d (need a multiple of 8, <= 512)", C);
+    PK_SUPPORTED(C >= 8 && (C & 7) == 0 && C <= 1024, "pk_layernorm_fwd: C=%d (need a multiple of 8, <= 1024)", C);
+    const int Cr = C_real > 0 ? C_real : C;
+    PK_REQUIRE(Cr <= C, "pk_layernorm_fwd: C_real=%d > C=%d", Cr, C);
     hipStream_t st = (hipStream_t)stream;
     const uint4* X = (const uint4*)x;
     uint4* Y = (uint4*)y;
+    if (C > 512) {
+        LN_DISPATCH(k_ln_fwd, 64, 2, X, gamma, beta, Y, save_mean, save_rstd, rows, C, Cr, eps);
+        return pk_launch_status("pk_layernorm_fwd");
+    }
     switch (ln_lanes(C)) {
-        case 1: LN_DISPATCH(k_ln_fwd, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
-        case 2: LN_DISPATCH(k_ln_fwd, 2, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
-        case 4: LN_DISPATCH(k_ln_fwd, 4, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
-        case 8: LN_DISPATCH(k_ln_fwd, 8, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
-        case 16: LN_DISPATCH(k_ln_fwd, 16, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
-        case 32: LN_DISPATCH(k_ln_fwd, 32, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
-        default: LN_DISPATCH(k_ln_fwd, 64, X, gamma, beta, Y, save_mean, save_rstd, rows, C, eps); break;
+        case 1: LN_DISPATCH(k_ln_fwd, 1, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, Cr, eps); break;
+        case 2: LN_DISPATCH(k_ln_fwd, 2, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, Cr, eps); break;
+        case 4: LN_DISPATCH(k_ln_fwd, 4, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, Cr, eps); break;
+        case 8: LN_DISPATCH(k_ln_fwd, 8, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, Cr, eps); break;
+        case 16: LN_DISPATCH(k_ln_fwd, 16, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, Cr, eps); break;
+        case 32: LN_DISPATCH(k_ln_fwd, 32, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, Cr, eps); break;
+        default: LN_DISPATCH(k_ln_fwd, 64, 1, X, gamma, beta, Y, save_mean, save_rstd, rows, C, Cr, eps); break;
     }
     return pk_launch_status("pk_layernorm_fwd");
 }
 
 // dx = rstd*(gh - mean_c(gh) - xhat*mean_c(gh*xhat)) (+ dres), gh = dy*gamma; per-block partials of dgamma/dbeta.
 // Each block owns `rows_per_block` consecutive rows so its column partials can be reduced deterministically.
-template <int L>
+template <int L, int CPL>
 __global__ void __launch_bounds__(256) k_ln_bwd(const uint4* __restrict__ dy, const uint4* __restrict__ x, const float* __restrict__ mean,
                                                 const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                 const uint4* __restrict__ dres, uint4* __restrict__ dx, float* __restrict__ part,
-                                                int64_t rows, int C, int rows_per_block) {
+                                                int64_t rows, int C, int Cr, int rows_per_block) {
     __shared__ float sh[256 * 16];
     const int cchunks = C / 8, sub = threadIdx.x % L, rl = threadIdx.x / L, rlanes = 256 / L;
-    float ag[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ab[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gm[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) gm[j] = (sub < cchunks) ? gamma[sub * 8 + j] : 0.f;
+    float* dst = part + (size_t)blockIdx.x * 2 * C;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + (int64_t)rows_per_block);
+    float ag[CPL][8], ab[CPL][8], gm[CPL][8];
+#pragma unroll
+    for (int c = 0; c < CPL; ++c)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int col = (sub + c * L) * 8 + j;
+            ag[c][j] = ab[c][j] = 0.f;
+            gm[c][j] = (col < Cr) ? gamma[col] : 0.f;
+        }
     for (int64_t rb = r0; rb < r1; rb += rlanes) {        // uniform trip count: every lane executes the shuffles
         const int64_t row = rb + rl;
-        const bool on = row < r1 && sub < cchunks;
-        float g[8] = {0, 0, 0, 0, 0, 0, 0, 0}, v[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xh[8];
+        float g[CPL][8], xh[CPL][8];
         float mu = 0.f, rs = 0.f;
-        if (on) {
-            unpack8(dy[(size_t)row * cchunks + sub], g);
-            unpack8(x[(size_t)row * cchunks + sub], v);
+        if (row < r1) {
             mu = mean[row];
             rs = rstd[row];
         }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            xh[j] = (v[j] - mu) * rs;
-            const float gh = g[j] * gm[j];
-            s1 += gh;
-            s2 += gh * xh[j];
-            ag[j] += g[j] * xh[j];
-            ab[j] += g[j];
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = sub + c * L;
+            const bool on = row < r1 && ch < cchunks;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g[c][j] = 0.f;
+            if (on) {
+                unpack8(dy[(size_t)row * cchunks + ch], g[c]);
+                unpack8(x[(size_t)row * cchunks + ch], v);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool real = ch * 8 + j < Cr;
+                xh[c][j] = real ? (v[j] - mu) * rs : 0.f;
+                if (!real) g[c][j] = 0.f;
+                const float gh = g[c][j] * gm[c][j];
+                s1 += gh;
+                s2 += gh * xh[c][j];
+                ag[c][j] += g[c][j] * xh[c][j];
+                ab[c][j] += g[c][j];
+            }
         }
 #pragma unroll
         for (int o = 1; o < L; o <<= 1) {
             s1 += __shfl_xor(s1, o, 64);
             s2 += __shfl_xor(s2, o, 64);
         }
-        if (on) {
+        const float m1 = s1 / (float)Cr, m2 = s2 / (float)Cr;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) {
+            const int ch = sub + c * L;
+            if (!(row < r1 && ch < cchunks)) continue;
             float o8[8], r8[8];
-            if (dres) unpack8(dres[(size_t)row * cchunks + sub], r8);
-            const float m1 = s1 / (float)C, m2 = s2 / (float)C;
+            if (dres) unpack8(dres[(size_t)row * cchunks + ch], r8);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                o8[j] = rs * (g[j] * gm[j] - m1 - xh[j] * m2);
+                o8[j] = (ch * 8 + j < Cr) ? rs * (g[c][j] * gm[c][j] - m1 - xh[c][j] * m2) : 0.f;
                 if (dres) o8[j] += r8[j];
             }
-            dx[(size_t)row * cchunks + sub] = pack8(o8);
+            dx[(size_t)row * cchunks + ch] = pack8(o8);
         }
     }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        sh[threadIdx.x * 16 + j] = ag[j];
-        sh[threadIdx.x * 16 + 8 + j] = ab[j];
-    }
-    __syncthreads();
-    if (threadIdx.x < cchunks) {
-        float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        for (int k = 0; k < rlanes; ++k) {
-            const int t = k * L + threadIdx.x;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                a1[j] += sh[t * 16 + j];
-                a2[j] += sh[t * 16 + 8 + j];
-            }
-        }
-        float* dst = part + (size_t)blockIdx.x * 2 * C;
+    for (int c = 0; c < CPL; ++c) {
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            dst[threadIdx.x * 8 + j] = a1[j];
-            dst[C + threadIdx.x * 8 + j] = a2[j];
+            sh[threadIdx.x * 16 + j] = ag[c][j];
+            sh[threadIdx.x * 16 + 8 + j] = ab[c][j];
+        }
+        __syncthreads();
+        const int ch = threadIdx.x + c * L;
+        if (threadIdx.x < L && ch < cchunks) {
+            float a1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, a2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int k = 0; k < rlanes; ++k) {
+                const int t = k * L + threadIdx.x;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    a1[j] += sh[t * 16 + j];
+                    a2[j] += sh[t * 16 + 8 + j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                dst[ch * 8 + j] = a1[j];
+                dst[C + ch * 8 + j] = a2[j];
+            }
         }
     }
 }
@@ -409,23 +459,26 @@ extern "C" int pk_ln_bwd_blocks(int64_t rows) {
 }
 extern "C" int pk_layernorm_bwd(const void* dy, const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
                                 const void* dresidual, void* dx, float* partial, float* dgamma, float* dbeta, int64_t rows, int C,
-                                void* stream) {
+                                int C_real, void* stream) {
     PK_REQUIRE(dy && x && save_mean && save_rstd && gamma && dx && partial && dgamma && dbeta && rows > 0, "pk_layernorm_bwd: bad argument");
-    PK_SUPPORTED(C >= 8 && (C & 7) == 0 && C <= 512, "pk_layernorm_bwd: C=%d", C);
+    PK_SUPPORTED(C >= 8 && (C & 7) == 0 && C <= 1024, "pk_layernorm_bwd: C=%d", C);
+    const int Cr = C_real > 0 ? C_real : C;
+    PK_REQUIRE(Cr <= C, "pk_layernorm_bwd: C_real=%d > C=%d", Cr, C);
     hipStream_t st = (hipStream_t)stream;
     const int nb = pk_ln_bwd_blocks(rows);
     const int rpb = (int)((rows + nb - 1) / nb);
     const uint4 *DY = (const uint4*)dy, *X = (const uint4*)x, *DR = (const uint4*)dresidual;
     uint4* DX = (uint4*)dx;
-#define LNB(L) hipLaunchKernelGGL((k_ln_bwd<L>), dim3(nb), dim3(256), 0, st, DY, X, save_mean, save_rstd, gamma, DR, DX, partial, rows, C, rpb)
-    switch (ln_lanes(C)) {
-        case 1: LNB(1); break;
-        case 2: LNB(2); break;
-        case 4: LNB(4); break;
-        case 8: LNB(8); break;
-        case 16: LNB(16); break;
-        case 32: LNB(32); break;
-        default: LNB(64); break;
+#define LNB(L, CPL) hipLaunchKernelGGL((k_ln_bwd<L, CPL>), dim3(nb), dim3(256), 0, st, DY, X, save_mean, save_rstd, gamma, DR, DX, partial, rows, C, Cr, rpb)
+    if (C > 512) LNB(64, 2);
+    else switch (ln_lanes(C)) {
+        case 1: LNB(1, 1); break;
+        case 2: LNB(2, 1); break;
+        case 4: LNB(4, 1); break;
+        case 8: LNB(8, 1); break;
+        case 16: LNB(16, 1); break;
+        case 32: LNB(32, 1); break;
+        default: LNB(64, 1); break;
     }
 #undef LNB
     hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, (float*)nullptr, 1.f, 0, dgamma,

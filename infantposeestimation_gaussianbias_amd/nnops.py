@@ -351,22 +351,23 @@ def window_rowmap(B, H, W, device):
     return _MAPS[key]
 
 
-def _layernorm(x2d, gamma, beta):
+def _layernorm(x2d, gamma, beta, c_real=0):
+    """c_real: number of real channels when the rows are zero-padded (padded twin of HRFormer-base), 0 = all."""
     M, C = x2d.shape
     y = _e((M, C), BF16, x2d.device)
     mean, rstd = _e((M,), F32, x2d.device), _e((M,), F32, x2d.device)
-    call("pk_layernorm_fwd", x2d, gamma, beta, y, mean, rstd, M, C, 1e-5, stream_ptr())
+    call("pk_layernorm_fwd", x2d, gamma, beta, y, mean, rstd, M, C, c_real, 1e-5, stream_ptr())
     return y, mean, rstd
 
 
-def _layernorm_bwd(dy, x2d, mean, rstd, gamma, dres, g_param=None, b_param=None):
+def _layernorm_bwd(dy, x2d, mean, rstd, gamma, dres, g_param=None, b_param=None, c_real=0):
     M, C = x2d.shape
     nb = _lib.lib.pk_ln_bwd_blocks(M)
     part = _e((nb, 2, C), F32, x2d.device)
     dx = _e((M, C), BF16, x2d.device)
     (dg, sg) = _sink(g_param) if g_param is not None else (_e((C,), F32, x2d.device), False)
     (db, sb) = _sink(b_param) if b_param is not None else (_e((C,), F32, x2d.device), False)
-    call("pk_layernorm_bwd", dy, x2d, mean, rstd, gamma, dres, dx, part, dg, db, M, C, stream_ptr())
+    call("pk_layernorm_bwd", dy, x2d, mean, rstd, gamma, dres, dx, part, dg, db, M, C, c_real, stream_ptr())
     return dx, (None if sg else dg), (None if sb else db)
 
 
@@ -382,8 +383,9 @@ class _AttnHalf(torch.autograd.Function):
     """x + s1 * proj(window_attention(qkv(LN1(x))))   on (B,H,W,C) bf16."""
 
     @staticmethod
-    def forward(ctx, x, g1, b1, table, wqkv, bqkv, wproj, bproj, scale1, heads):
+    def forward(ctx, x, g1, b1, table, wqkv, bqkv, wproj, bproj, scale1, heads, c_real=0, attn_scale=0.0):
         ctx.params = (g1, b1, table, wqkv, bqkv, wproj, bproj)
+        ctx.pad = (c_real, attn_scale)
         wc = _wc()
         x = x.contiguous()
         B, H, W, C = x.shape
@@ -391,11 +393,11 @@ class _AttnHalf(torch.autograd.Function):
         amap, nwin = window_rowmap(B, H, W, x.device)
         Mw = B * nwin * WS * WS
         x2 = x.view(M, C)
-        u, mean, rstd = _layernorm(x2, g1, b1)
+        u, mean, rstd = _layernorm(x2, g1, b1, c_real)
         qkv = _linear(u, wc.fwd[id(wqkv)], Mw, 3 * C, C, bias=bqkv, a_map=amap)
         o = _e((Mw, C), BF16, x.device)
         lse = _e((B * nwin * heads * WS * WS,), F32, x.device)
-        call("pk_window_attn_fwd", qkv, table, o, lse, B * nwin, heads, C, 0.0, stream_ptr())
+        call("pk_window_attn_fwd", qkv, table, o, lse, B * nwin, heads, C, attn_scale, stream_ptr())
         s1 = None if scale1 is None else scale1.float().contiguous()
         y = _linear(o, wc.fwd[id(wproj)], M, C, C, bias=bproj, residual=x2, res_scale=s1, o_map=amap, M=Mw, rps=H * W)
         ctx.save_for_backward(x2, u, mean, rstd, qkv, o, lse, g1, table, s1 if s1 is not None else x.new_empty(0),
@@ -422,29 +424,30 @@ class _AttnHalf(torch.autograd.Function):
         dqkv = _e((Mw, 3 * C), BF16, dev)
         part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads),), F32, dev)
         dtable, s_t = _sink(ptab)
-        call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, 0.0, stream_ptr())
+        call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, ctx.pad[1], stream_ptr())
         # qkv linear: scatter the token gradients back to pixel rows (pad tokens dropped)
         du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
         dst, s_wq = _sink(pwqkv)
         dbqkv, s_bq = _sink(pbqkv)
         dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw, out=dst, dbias=dbqkv, deferred=s_wq and s_bq)
-        dx, dg1, db1 = _layernorm_bwd(du, x2, mean, rstd, g1, dy2, pg1, pb1)
+        dx, dg1, db1 = _layernorm_bwd(du, x2, mean, rstd, g1, dy2, pg1, pb1, ctx.pad[0])
         return (dx.view(B, H, W, C), dg1, db1, None if s_t else dtable, None if s_wq else dwqkv, None if s_bq else dbqkv,
-                None if s_wp else dwproj, None if s_bp else dbproj, None, None)
+                None if s_wp else dwproj, None if s_bp else dbproj, None, None, None, None)
 
 
 class _MlpHalf(torch.autograd.Function):
     """x + s2 * fc2(gelu(fc1(LN2(x))))   on (B,H,W,C) bf16."""
 
     @staticmethod
-    def forward(ctx, x, g2, b2, w1, bias1, w2, bias2, scale2):
+    def forward(ctx, x, g2, b2, w1, bias1, w2, bias2, scale2, c_real=0):
         ctx.params = (g2, b2, w1, bias1, w2, bias2)
+        ctx.c_real = c_real
         wc = _wc()
         x = x.contiguous()
         B, H, W, C = x.shape
         M, Hd = B * H * W, w1.shape[0]
         x2 = x.view(M, C)
-        v, mean, rstd = _layernorm(x2, g2, b2)
+        v, mean, rstd = _layernorm(x2, g2, b2, c_real)
         z = _e((M, Hd), BF16, x.device)
         h = _linear(v, wc.fwd[id(w1)], M, Hd, C, bias=bias1, preact=z, act=1)
         s2 = None if scale2 is None else scale2.float().contiguous()
@@ -469,17 +472,18 @@ class _MlpHalf(torch.autograd.Function):
         dst, s_w1 = _sink(pw1)
         db1, s_b1 = _sink(pbias1)
         dw1 = _wgrad(v, dz, Hd, C, 1, 1, None, M=M, out=dst, dbias=db1, deferred=s_w1 and s_b1)
-        dx, dg2, dbt2 = _layernorm_bwd(dv, x2, mean, rstd, g2, dy2, pg2, pb2)
+        dx, dg2, dbt2 = _layernorm_bwd(dv, x2, mean, rstd, g2, dy2, pg2, pb2, ctx.c_real)
         return (dx.view(B, H, W, C), dg2, dbt2, None if s_w1 else dw1, None if s_b1 else db1, None if s_w2 else dw2,
-                None if s_b2 else db2, None)
+                None if s_b2 else db2, None, None)
 
 
 def window_block(x, blk, heads, scale1=None, scale2=None):
     a = blk.attn
+    c_real, attn_scale = getattr(blk, "c_real", 0), getattr(blk, "attn_scale", 0.0)      # set on padded twins (models/padded.py)
     x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
-                        a.proj.weight, a.proj.bias, scale1, heads)
+                        a.proj.weight, a.proj.bias, scale1, heads, c_real, attn_scale)
     m = blk.mlp
-    return _MlpHalf.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2)
+    return _MlpHalf.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2, c_real)
 
 
 # ================================================================================================ exchange unit
@@ -562,7 +566,7 @@ def drop_scales(n_draws, batch, drop_prob, device):
 
 # ================================================================================================ backend choice
 def supported(model) -> bool:
-    """True when every conv / linear of `model` fits the HIP kernels (channels % 8 == 0, head_dim in {8,16,24,32})."""
+    """True when every conv / linear of `model` fits the HIP kernels (channels % 8 == 0, head_dim a multiple of 8 up to 64)."""
     for m in model.modules():
         if isinstance(m, torch.nn.Conv2d):
             if m.weight.shape[0] % 8 and m.weight.shape[2] != 1:
@@ -571,7 +575,7 @@ def supported(model) -> bool:
                 return False
         if hasattr(m, "relative_position_bias_table"):
             d = m.qkv.weight.shape[1] // m.relative_position_bias_table.shape[1]
-            if d > 32 or d % 8:
+            if d > 64 or d % 8:
                 return False
         if isinstance(m, torch.nn.LayerNorm) and m.normalized_shape[0] % 8:
             return False

@@ -199,6 +199,29 @@ def test_layernorm_fwd_bwd(N, C_):
     assert err(C(dg), gr.grad) < 2e-3 and err(C(db), br.grad) < 2e-3
 
 
+@pytest.mark.parametrize("Cr,Cp", [(78, 80), (156, 160), (312, 320), (624, 640), (640, 640)])
+def test_layernorm_padded_rows(N, Cr, Cp):
+    """Rows of Cp channels of which the first Cr are real (zero padding behind): LayerNorm over the real channels only,
+    padded outputs and input gradients exactly zero (HRFormer-base's C=78/156/312/624 in 8-aligned rows)."""
+    M = 23 * 7
+    x, g, b = rnd(M, Cr, seed=1, scale=2.0), torch.rand(Cr) + 0.5, torch.randn(Cr) * 0.1
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    y_ref = F.layer_norm(xr, (Cr,), gr, br, 1e-5)
+    gy, dres = rnd(M, Cr, seed=2), rnd(M, Cr, seed=3)
+    y_ref.backward(gy)
+    pad = lambda t: F.pad(t, (0, Cp - Cr))
+    y, mean, rstd = N._layernorm(pad(x).to(DEV, BF), pad(g).to(DEV), pad(b).to(DEV), Cr)
+    yc = C(y)
+    assert err(yc[:, :Cr], y_ref.detach()) < 8e-3 and float(yc[:, Cr:].abs().max() if Cp > Cr else 0) == 0.0
+    # garbage in the padded columns of dy must not leak (they are zero in practice; the kernel masks them anyway)
+    gy_p = pad(gy).clone()
+    gy_p[:, Cr:] = 3.0
+    dx, dg, db = N._layernorm_bwd(gy_p.to(DEV, BF), pad(x).to(DEV, BF), mean, rstd, pad(g).to(DEV), pad(dres).to(DEV, BF), c_real=Cr)
+    dxc = C(dx)
+    assert err(dxc[:, :Cr], xr.grad + dres) < 8e-3 and float(dxc[:, Cr:].abs().max() if Cp > Cr else 0) == 0.0
+    assert err(C(dg)[:Cr], gr.grad) < 2e-3 and err(C(db)[:Cr], br.grad) < 2e-3
+
+
 def test_linear_rowmaps_gelu_residual(N):
     from infantposeestimation_gaussianbias_amd._lib import call, stream_ptr
     B, H, W, Cc, Nn = 2, 9, 10, 32, 96

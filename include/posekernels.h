@@ -188,6 +188,14 @@ int pk_nchw_f32_to_nhwc_bf16(const float* x, const float* softplus_out, void* y,
  * mode 0: dst[n][t][cp]=src[n][c][t] (forward), 1: dst[c][T-1-t][np]=src[n][c][t] (conv data-grad), 2: dst[c][np]=src[n][c] */
 int pk_pack_weights(void* flat_dst_bf16, const void* desc_table, const int32_t* block_desc, const int32_t* block_first,
                     int n_blocks, void* stream);
+/* Padded twins (models whose channel counts are not multiples of 8, e.g. HRFormer-base C=78, head_dim 39 -- hrformer.py:779-825):
+ * every real fp32 tensor is a box r[4] at the origin of the twin's box p[4] inside one flat twin buffer.
+ * desc_table rows (56 bytes): { float* real; int64 twin_off; int r[4]; int p[4]; int64 numel; }; one 256-thread block per
+ * 1024 real elements (block_desc = row index, block_first = first block of that row).
+ * direction 0: twin <- real (parameters, buffers); 1: real <- twin (gradients into a sink, BatchNorm running statistics);
+ * 2: real += twin (accumulate into .grad).                                                                              */
+int pk_embed_boxes(float* twin_base, const void* desc_table, const int* block_desc, const int* block_first, int n_blocks,
+                   int direction, void* stream);
 
 #ifdef __cplusplus
 }

@@ -717,3 +717,39 @@ extern "C" int pk_pack_weights(void* flat_dst_bf16, const void* desc_table, cons
                        (const PackDesc*)desc_table, block_desc, block_first);
     return pk_launch_status("pk_pack_weights");
 }
+
+// ================================================================================================ padded twins
+// A model whose channel counts are not multiples of 8 (HRFormer-base: C = 78/156/312/624, head_dim 39) runs through a
+// "padded twin" with 8-aligned shapes.  Every real tensor is a box r[0..3] embedded at the origin of the twin's box p[0..3]
+// (plain zero-extension, or head-structured: qkv rows (3, heads, 39 -> 40, C -> Cp), proj columns (C -> Cp, heads, 39 -> 40)).
+// direction 0: twin[box] = real (parameters / buffers before a forward); 1: real = twin[box] (gradients into a gradient
+// sink, BatchNorm running statistics after a step); 2: real += twin[box] (autograd-style accumulation into `.grad`).
+// Table driven: ONE launch per direction for the whole model.
+struct EmbedDesc { float* real; int64_t twin_off; int r[4]; int p[4]; int64_t numel; };
+__global__ void __launch_bounds__(256) k_embed_boxes(float* __restrict__ twin, const EmbedDesc* __restrict__ desc,
+                                                     const int* __restrict__ blk_desc, const int* __restrict__ blk_first, int direction) {
+    const EmbedDesc d = desc[blk_desc[blockIdx.x]];
+    const int64_t i0 = (int64_t)(blockIdx.x - blk_first[blockIdx.x]) * 1024;
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = i0 + k * 256 + threadIdx.x;
+        if (i >= d.numel) return;
+        int64_t t = i;
+        const int i3 = (int)(t % d.r[3]);
+        t /= d.r[3];
+        const int i2 = (int)(t % d.r[2]);
+        t /= d.r[2];
+        const int i1 = (int)(t % d.r[1]), i0_ = (int)(t / d.r[1]);
+        const int64_t j = d.twin_off + (((int64_t)i0_ * d.p[1] + i1) * d.p[2] + i2) * d.p[3] + i3;
+        if (direction == 0) twin[j] = d.real[i];
+        else if (direction == 1) d.real[i] = twin[j];
+        else d.real[i] += twin[j];
+    }
+}
+extern "C" int pk_embed_boxes(float* twin_base, const void* desc_table, const int* block_desc, const int* block_first, int n_blocks,
+                              int direction, void* stream) {
+    PK_REQUIRE(twin_base && desc_table && block_desc && block_first && n_blocks > 0 && direction >= 0 && direction <= 2,
+               "pk_embed_boxes: bad argument");
+    hipLaunchKernelGGL(k_embed_boxes, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, twin_base, (const EmbedDesc*)desc_table, block_desc,
+                       block_first, direction);
+    return pk_launch_status("pk_embed_boxes");
+}

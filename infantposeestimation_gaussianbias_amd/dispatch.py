@@ -23,7 +23,17 @@ def backend_for(model):
     return nnops if name == "hip" else nnops_aten
 
 
+def padded_twin(model):
+    """8-aligned twin of a model whose channel counts the HIP kernels cannot take (models/padded.py), else None."""
+    if getattr(model, "_pk_twin", None) is False:
+        return None
+    from .models import padded
+    return padded.twin_for(model)
+
+
 def backend_name(model) -> str:
+    if torch.cuda.is_available() and padded_twin(model) is not None:
+        return "hip (8-aligned padded twin)"
     backend_for(model)
     return model._pk_backend
 

@@ -126,6 +126,9 @@ class FlatAdamW:
         wc = getattr(self.model, "_pk_weight_cache", None)
         if wc is not None:
             wc.mark_dirty()          # the kernel rewrote the fp32 masters behind torch's back: bf16 copies are stale
+        tw = getattr(self.model, "_pk_twin", None)
+        if tw:
+            tw.mark_dirty()          # ... and so is the padded twin's embedded copy
 
     # -- checkpoint format of the reference (train.py:351-357): per-parameter state keyed by index ---------------
     def state_dict(self):
@@ -318,6 +321,9 @@ class Trainer:
         out["loss"].backward()
         from . import dispatch
         dispatch.join_aux()            # weight-gradient kernels issued on auxiliary streams (dispatch.aux_stream_for)
+        tw = getattr(self.model, "_pk_twin", None)
+        if tw:
+            tw.grads_to_real()         # padded twin: no-op when the end-of-backward callback already extracted the gradients
         return out
 
     def _eager_step(self, batch):

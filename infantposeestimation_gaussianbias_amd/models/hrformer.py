@@ -94,6 +94,7 @@ class HRFormer(nn.Module):
                  stage4_num_channels=(78, 156, 312, 624), stage4_num_heads=(2, 4, 8, 16), stage4_mlp_ratios=(4, 4, 4, 4),
                  stage4_window_sizes=(7, 7, 7, 7)):
         super().__init__()
+        self._ctor = {k: v for k, v in locals().items() if k not in ("self", "__class__")}      # to rebuild a padded twin (models/padded.py)
         if not with_rpe:
             raise ValueError("with_rpe=False is not supported by the fused window-attention kernels")
         for ws in (*stage2_window_sizes, *stage3_window_sizes, *stage4_window_sizes):
@@ -116,6 +117,9 @@ class HRFormer(nn.Module):
         init_backbone_weights(self)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        tw = nnops.padded_twin(self)
+        if tw is not None:                       # C % 8 != 0 (HRFormer-base): run the 8-aligned twin, hand back the real channels
+            return tw.run(x)[:, :self.out_channels]
         with nnops.scope(self):
             return nnops.to_public(self._forward(x))
 

@@ -32,22 +32,28 @@ class HighResolutionModule(nn.Module):
 
 
 class HRNet(nn.Module):
-    def __init__(self, in_channels: int = 3, base_channels: int = 32):
+    def __init__(self, in_channels: int = 3, base_channels: int = 32, _stage_channels=None):
+        """`_stage_channels` (4 ints) overrides base_channels * 2^i: used for 8-aligned padded twins (models/padded.py)."""
         super().__init__()
         c = self.base_channels = base_channels
+        self.in_channels = in_channels
+        self.stage_channels = list(_stage_channels) if _stage_channels is not None else [c * (2 ** i) for i in range(4)]
         self.conv1, self.bn1 = conv(in_channels, 64, 3, 2), nn.BatchNorm2d(64)
         self.conv2, self.bn2 = conv(64, 64, 3, 2), nn.BatchNorm2d(64)
         self.layer1 = nn.ModuleList(Residual(64 if i == 0 else 256, 64, True, project=(i == 0)) for i in range(4))
         pre = [256]
         for s, nm in ((2, 1), (3, 4), (4, 3)):
-            ch = [c * (2 ** i) for i in range(s)]
+            ch = self.stage_channels[:s]
             setattr(self, f"transition{s - 1}", make_transition(pre, ch))
             setattr(self, f"stage{s}", nn.ModuleList(HighResolutionModule(ch, [4] * s) for _ in range(nm)))
             pre = ch
-        self.out_channels = c
+        self.out_channels = self.stage_channels[0]
         init_backbone_weights(self)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
+        tw = nnops.padded_twin(self)
+        if tw is not None:                       # C % 8 != 0 (HRNet-W18): run the 8-aligned twin, hand back the real channels
+            return tw.run(x)[:, :self.out_channels]
         with nnops.scope(self):
             return nnops.to_public(self._forward(x))
 

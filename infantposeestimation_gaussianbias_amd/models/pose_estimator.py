@@ -62,7 +62,28 @@ class PoseEstimator(nn.Module):
         self.num_keypoints = num_keypoints
         self.soft_argmax = SoftArgmax2D()
 
+    @classmethod
+    def from_backbone(cls, backbone_module: nn.Module, in_channels: int, num_keypoints: int, head_type: str, use_fusion_loss: bool):
+        """Same composition as __init__ around an already-built backbone (used for 8-aligned padded twins)."""
+        self = cls.__new__(cls)
+        nn.Module.__init__(self)
+        self.head_type = head_type
+        self.use_fusion_loss = use_fusion_loss and head_type == "fusion"
+        self.backbone = backbone_module
+        if head_type == "fusion":
+            self.head = HeatmapRegressionHead(in_channels, num_keypoints, 256, True)
+            self.loss_fn = FusionPoseLoss(1.0, 1.0, 0.5, 0.1, 0.05, 0.05, 2.0, True)
+        else:
+            self.head = HeatmapHead(in_channels, num_keypoints, 0)
+            self.loss_fn = KeypointMSELoss(True)
+        self.num_keypoints = num_keypoints
+        self.soft_argmax = SoftArgmax2D()
+        return self
+
     def forward(self, x, target=None, target_weight=None, gt_keypoints=None, input_size: Tuple[int, int] = (192, 256)) -> Dict[str, torch.Tensor]:
+        tw = nnops.padded_twin(self)
+        if tw is not None:                       # backbone channels not multiples of 8: the whole estimator runs as its 8-aligned twin
+            return tw.run(x, target, target_weight, gt_keypoints, input_size)
         with nnops.scope(self):
             feats = self.backbone(x)
             output = dict(self.head(feats)) if self.head_type == "fusion" else {"heatmaps": self.head(feats)}

@@ -33,7 +33,12 @@ def _e(shape, dtype, dev):
 # then store that parameter's gradient THERE (plain store: every parameter is used once per step) and hand None to autograd,
 # which removes ~800 `grad += g` launches per step.  Set by engine.FlatAdamW(direct_grads=True); absent = ordinary autograd.
 def grad_sink_of(param):
-    return getattr(param, "_pk_grad_sink", None)
+    """Called by backward functions only (and by the padded twin for the real parameters): a parameter whose sink was asked
+    for has received a gradient this step (`_pk_used`; the padded twin extracts only those, others keep grad=None)."""
+    dst = getattr(param, "_pk_grad_sink", None)
+    if dst is not None:
+        param._pk_used = True
+    return dst
 
 
 def _sink(param):

@@ -113,7 +113,7 @@ def main():
     if args.gpus != world and rank == 0:
         print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
-    from infantposeestimation_gaussianbias_amd import dispatch, engine, nnops, nnops_aten
+    from infantposeestimation_gaussianbias_amd import dispatch, engine, nnops
     from infantposeestimation_gaussianbias_amd.configs import get_config
     from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
     from infantposeestimation_gaussianbias_amd.models import build_model
@@ -164,7 +164,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
             log(f"cpu baseline: {cpu}")
-        impl_table = nnops.IMPL if dispatch.backend_name(model) == "hip" else nnops_aten.IMPL
+        impl_table = nnops.IMPL
         n_hip = sum(v == "hip" for v in impl_table.values())
         line = {
             "metric": "images/sec (train fwd+bwd) HRFormer-S 256x192", "value": round(PER_GPU_BATCH * world * args.steps / dt, 2),
@@ -177,7 +177,7 @@ def main():
                        (", branches on concurrent HIP streams" if dispatch.streams_enabled() else ", single stream")},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
             "impl": dict(impl_table, loss="hip", target="hip", decode="hip", adamw="hip"),
-            "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP; 'aten' entries are PyTorch-ROCm stop-gaps",
+            "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP ({dispatch.backend_name(model)}); no PyTorch/CPU fallback exists",
         }
         print(json.dumps(line))
     if world > 1:

@@ -1,26 +1,31 @@
-"""Per-model backend selection for the network ops.
+"""Entry to the network ops (`nnops`: hand-written HIP kernels, NHWC bf16 tensors).
 
-`with dispatch.scope(model):` activates, for the duration of a forward pass, either `nnops` (hand-written HIP
-kernels, NHWC bf16 tensors, bf16 weight cache refreshed on entry) when every layer of `model` fits the kernels, or
-`nnops_aten` (PyTorch-ROCm composites, channels_last tensors) otherwise.  Nested scopes reuse the outer one, so a
-backbone called from PoseEstimator shares its weight cache.  `backend_name(model)` reports the choice.
+`with dispatch.scope(model):` activates the kernels for the duration of a forward pass and refreshes the model's bf16 weight
+cache on entry; nested scopes reuse the outer one, so a backbone called from PoseEstimator shares its cache.  A model whose
+channel counts are not multiples of 8 (HRFormer-base, HRNet-W18) is run through its 8-aligned padded twin
+(`padded_twin`, models/padded.py); a model that fits neither raises -- there is no PyTorch or CPU fallback.
 """
 import contextlib
 import os
 
 import torch
 
-from . import nnops, nnops_aten
+from . import nnops
+from ._lib import PoseKernelError
 
 _ACTIVE = []
 
 
 def backend_for(model):
-    name = getattr(model, "_pk_backend", None)
-    if name is None:
-        name = "hip" if nnops.supported(model) else "aten"
-        object.__setattr__(model, "_pk_backend", name)
-    return nnops if name == "hip" else nnops_aten
+    ok = getattr(model, "_pk_supported", None)
+    if ok is None:
+        ok = nnops.supported(model)
+        object.__setattr__(model, "_pk_supported", ok)
+    if not ok:
+        raise PoseKernelError(
+            f"{type(model).__name__}: layer shapes outside the HIP kernels (channels must be multiples of 8, head_dim a multiple of 8 "
+            "up to 64, window 7) and no 8-aligned padded twin could be built (models/padded.py); there is no fallback path")
+    return nnops
 
 
 def padded_twin(model):
@@ -35,7 +40,7 @@ def backend_name(model) -> str:
     if torch.cuda.is_available() and padded_twin(model) is not None:
         return "hip (8-aligned padded twin)"
     backend_for(model)
-    return model._pk_backend
+    return "hip"
 
 
 @contextlib.contextmanager
@@ -46,10 +51,7 @@ def scope(model):
     ops = backend_for(model)
     _ACTIVE.append(ops)
     try:
-        if ops is nnops:
-            with nnops.use_weights(model):
-                yield ops
-        else:
+        with nnops.use_weights(model):
             yield ops
     finally:
         _ACTIVE.pop()
@@ -87,17 +89,17 @@ def drop_scales(n_draws, batch, drop_prob, device):
 
 def to_public(x):
     """Internal feature map -> the reference's (B,C,H,W) view (no copy)."""
-    return x.permute(0, 3, 1, 2) if ops() is nnops else x
+    ops()
+    return x.permute(0, 3, 1, 2)
 
 
 def from_public(x):
     """(B,C,H,W) feature map produced by one of our backbones (bf16) or a raw fp32 tensor -> internal layout."""
+    ops()
     if x.dtype != nnops.ACT_DTYPE:
-        if ops() is nnops:
-            B, C, H, W = x.shape
-            return nnops.to_features(x, cpad=-(-C // 8) * 8)
-        return nnops_aten.to_features(x)
-    return x.permute(0, 2, 3, 1).contiguous() if ops() is nnops else x
+        B, C, H, W = x.shape
+        return nnops.to_features(x, cpad=-(-C // 8) * 8)
+    return x.permute(0, 2, 3, 1).contiguous()
 
 
 # ---------------------------------------------------------------------------------------------- branch concurrency
@@ -272,7 +274,7 @@ def parallel(fns, inputs):
     results (one tensor per callable) in order.  `inputs[i]` is the list of tensors fns[i] reads (everything else it
     touches must be parameters or tensors it creates itself)."""
     n = len(fns)
-    if n == 1 or not streams_enabled() or ops() is not nnops:
+    if n == 1 or not streams_enabled():
         return [f(list(x)) for f, x in zip(fns, inputs)]
     if _REGION[0] and torch.is_grad_enabled():
         counts = [len(x) for x in inputs]

@@ -9,9 +9,9 @@ forward and backward are explicit sequences of C-ABI calls; torch only allocates
   mlp_half      A3        LN2 -> fc1 GEMM + GELU -> fc2 GEMM (+residual, DropPath)
   fuse_sum      A4        sum of branches with fused bilinear up-sampling (+ReLU)
 
-Shapes the kernels do not cover (channel counts that are not multiples of 8, head_dim > 32: HRFormer-base C=78/d=39,
-HRNet-W18) run on `nnops_aten` (PyTorch-ROCm composites) instead; `backend_for(model)` decides per model and
-`IMPL` reports it.  Neither path is a CPU fallback and neither touches oracle/.
+Channel counts must be multiples of 8 (16-byte bf16 chunks) and head_dim a multiple of 8 up to 64; models outside that
+(HRFormer-base C=78 / head_dim 39, HRNet-W18) run through an 8-aligned padded twin built from the same kernels
+(models/padded.py).  There is no PyTorch / CPU fallback and nothing here touches oracle/.
 """
 import numpy as np
 import torch

@@ -167,7 +167,8 @@ int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* s
 int pk_relu_bwd(const void* dy, const void* y, void* dx, int64_t numel, void* stream);
 /* nn.LayerNorm(C, eps 1e-5) over the channel dim of NHWC rows (hrformer.py:240,252,273,288).  C = row width (multiple of 8,
  * <= 1024); C_real (0 = C) = number of real channels when the rows carry zero padding: statistics over the real channels,
- * padded outputs / input gradients are zero, gamma/beta are read for the real channels only.                             */
+ * padded outputs / input gradients are zero.  gamma/beta (and dgamma/dbeta) have C entries, 16-byte aligned; the padded
+ * entries are ignored.                                                                                                  */
 int pk_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, float* save_mean, float* save_rstd,
                      int64_t rows, int C, int C_real, float eps, void* stream);
 int pk_ln_bwd_blocks(int64_t rows);                          /* partial needs blocks*2*C floats */

@@ -308,9 +308,15 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const uint4* __restrict__ x, con
     for (int c = 0; c < CPL; ++c) {
         const int ch = sub + c * L;
         if (!on[c]) continue;
+        // gamma / beta have C entries (the padded ones are ignored): unconditional 16-byte loads, select afterwards
+        const float4 g0 = *reinterpret_cast<const float4*>(gamma + ch * 8), g1 = *reinterpret_cast<const float4*>(gamma + ch * 8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(beta + ch * 8), b1 = *reinterpret_cast<const float4*>(beta + ch * 8 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-        for (int j = 0; j < 8; ++j)
-            v[c][j] = (ch * 8 + j < Cr) ? (v[c][j] - mean) * rstd * gamma[ch * 8 + j] + beta[ch * 8 + j] : 0.f;
+        for (int j = 0; j < 8; ++j) {
+            const float t = (v[c][j] - mean) * rstd * gg[j] + bb[j];
+            v[c][j] = (ch * 8 + j < Cr) ? t : 0.f;
+        }
         y[(size_t)row * cchunks + ch] = pack8(v[c]);
     }
     if (sub == 0 && row < rows) {
@@ -371,7 +377,8 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const uint4* __restrict__ dy, co
         for (int j = 0; j < 8; ++j) {
             const int col = (sub + c * L) * 8 + j;
             ag[c][j] = ab[c][j] = 0.f;
-            gm[c][j] = (col < Cr) ? gamma[col] : 0.f;
+            gm[c][j] = (col < C) ? gamma[col] : 0.f;      // C entries; padded columns are masked where they are used
+            if (col >= Cr) gm[c][j] = 0.f;
         }
     for (int64_t rb = r0; rb < r1; rb += rlanes) {        // uniform trip count: every lane executes the shuffles
         const int64_t row = rb + rl;

@@ -135,6 +135,8 @@ int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, c
  * out_layout 0: [N][k*k][Cin]; 1: OIHW (the reference's nn.Conv2d.weight layout).  Ho == 0 selects the linear form.
  * dbias (optional, n_bias <= N entries): the bias gradient = column sums of the same (gathered, scaled) grad_out rows,
  * accumulated from the tile already staged in LDS.                                                                       */
+/* dw == NULL: write the slabs only (weight slabs [S][N*k*k*Cin], then bias slabs [S][N] when n_bias > 0) and let the caller
+ * reduce them later with pk_reduce_many.                                                                                  */
 int pk_wgrad_slices(int M, int N, int Cin, int T);
 int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, float* dbias, int n_bias,
                   const int32_t* a_rowmap, const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M, int N,
@@ -187,6 +189,12 @@ int pk_nchw_f32_to_nhwc_bf16(const float* x, const float* softplus_out, void* y,
 /* fp32 master weights -> bf16 compute copies, table driven, one launch for the whole model (see nnops.WeightCache).
  * desc_table: array of {const float* src; int64 dst_off; int N,C,T,mode,Cp,Np; int64 dst_numel} (48 bytes each);
  * mode 0: dst[n][t][cp]=src[n][c][t] (forward), 1: dst[c][T-1-t][np]=src[n][c][t] (conv data-grad), 2: dst[c][np]=src[n][c] */
+/* Deferred parameter-gradient reductions: ONE launch for any number of slab sums  out[index(i)] = sum_{s<S} part[s*slab_stride + i], i < K.
+ * desc_table rows (56 bytes): { const float* part; float* out; int64 slab_stride; int S, K, layout, N, T, Cin, out_stride, pad; };
+ * layout 0: index(i) = i*out_stride; layout 1: i = (n*T + t)*Cin + c -> OIHW (n*Cin + c)*T + t.  One 256-thread block per 16
+ * outputs (block_desc = row, block_first = first block of that row).  Producers: pk_wgrad_bf16 (dw NULL), pk_layernorm_bwd
+ * (dgamma/dbeta NULL: partial is [blocks][2C]), pk_window_attn_bwd (dtable NULL: partial is [groups][169]).                   */
+int pk_reduce_many(const void* desc_table, const int* block_desc, const int* block_first, int n_blocks, void* stream);
 int pk_pack_weights(void* flat_dst_bf16, const void* desc_table, const int32_t* block_desc, const int32_t* block_first,
                     int n_blocks, void* stream);
 /* Padded twins (models whose channel counts are not multiples of 8, e.g. HRFormer-base C=78, head_dim 39 -- hrformer.py:779-825):

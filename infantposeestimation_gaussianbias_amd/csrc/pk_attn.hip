@@ -433,7 +433,7 @@ extern "C" int pk_window_attn_bwd_ws_floats(int n_windows, int heads) { return p
 extern "C" int pk_window_attn_bwd(const void* qkv, const float* rel_table, const void* fwd_out, const void* dout, const float* lse,
                                   void* dqkv, float* dbias_partial, float* dtable, int n_windows, int heads, int C, float softmax_scale,
                                   void* stream) {
-    PK_REQUIRE(qkv && rel_table && fwd_out && dout && lse && dqkv && dbias_partial && dtable, "pk_window_attn_bwd: null pointer");
+    PK_REQUIRE(qkv && rel_table && fwd_out && dout && lse && dqkv && dbias_partial, "pk_window_attn_bwd: null pointer");
     PK_REQUIRE(((((uintptr_t)qkv) | ((uintptr_t)fwd_out) | ((uintptr_t)dout) | ((uintptr_t)dqkv)) & 15) == 0 && (C & 7) == 0,
                "pk_window_attn_bwd: alignment");
     PK_REQUIRE(n_windows > 0 && heads > 0 && C > 0 && C % heads == 0, "pk_window_attn_bwd: bad sizes");
@@ -448,6 +448,7 @@ extern "C" int pk_window_attn_bwd(const void* qkv, const float* rel_table, const
                        scale, groups / heads)
     ATTN_DISPATCH(d, LAUNCH_BWD);
 #undef LAUNCH_BWD
-    hipLaunchKernelGGL(k_relbias_reduce, dim3(169, heads), dim3(256), 0, st, dbias_partial, groups, heads, dtable);
+    if (dtable)      // NULL: partials only ([groups][169], group g belongs to head g % heads), reduced later by pk_reduce_many
+        hipLaunchKernelGGL(k_relbias_reduce, dim3(169, heads), dim3(256), 0, st, dbias_partial, groups, heads, dtable);
     return pk_launch_status("pk_window_attn_bwd");
 }

@@ -702,6 +702,41 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
     }
 }
 
+// Deferred parameter-gradient reductions.  Nothing in backward reads a parameter gradient, yet every split-M weight
+// gradient, LayerNorm dgamma/dbeta and rel-pos-bias gradient ended with its own small slab-reduce launch in the middle of
+// the data-gradient chain (~360 of the ~2 000 launches per step, each 6-12 us plus the dependency bubble around it).  With
+// dw/dgamma/dtable == NULL the producers only write their slabs; ONE table-driven launch at the end of backward reduces
+// them all:   out[index(i)] = sum_{s < S} part[s * slab_stride + i],  i < K
+//   layout 0: index(i) = i * out_stride;   layout 1 (conv OIHW): i = (n*T + t)*Cin + c  ->  (n*Cin + c)*T + t.
+// Block = 16 outputs x 16 slab-lanes, fixed-order combine (deterministic).
+struct ReduceDesc { const float* part; float* out; int64_t slab_stride; int S, K, layout, N, T, Cin, out_stride, pad_; };
+__global__ void __launch_bounds__(256) k_reduce_many(const ReduceDesc* __restrict__ desc, const int* __restrict__ blk_desc,
+                                                     const int* __restrict__ blk_first) {
+    __shared__ float sh[16][17];
+    const ReduceDesc d = desc[blk_desc[blockIdx.x]];
+    const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int i = (blockIdx.x - blk_first[blockIdx.x]) * 16 + col;
+    float s = 0.f;
+    if (i < d.K)
+        for (int k = rl; k < d.S; k += 16) s += d.part[(size_t)k * d.slab_stride + i];
+    sh[rl][col] = s;
+    __syncthreads();
+    if (rl != 0 || i >= d.K) return;
+    s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += sh[r][col];
+    if (d.layout == 0) d.out[(size_t)i * d.out_stride] = s;
+    else {
+        const int c = i % d.Cin, t = (i / d.Cin) % d.T, n = i / (d.Cin * d.T);
+        d.out[((size_t)n * d.Cin + c) * d.T + t] = s;
+    }
+}
+extern "C" int pk_reduce_many(const void* desc_table, const int* block_desc, const int* block_first, int n_blocks, void* stream) {
+    PK_REQUIRE(desc_table && block_desc && block_first && n_blocks > 0, "pk_reduce_many: bad argument");
+    hipLaunchKernelGGL(k_reduce_many, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, (const ReduceDesc*)desc_table, block_desc, block_first);
+    return pk_launch_status("pk_reduce_many");
+}
+
 static inline int wgrad_tile(int N, int Cin) { return (N >= 128 && Cin >= 128) ? 128 : 64; }
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
     // enough workgroups to fill 256 CUs several times over (>= 2048), but no slice shorter than 256 rows
@@ -721,7 +756,7 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
                              const int32_t* a_rowmap, const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M,
                              int N, int Cin, int ksize, int stride, int B, int Hs, int Ws, int Ho, int Wo, int out_layout,
                              void* stream) {
-    PK_REQUIRE(x && grad_out && workspace && dw, "pk_wgrad_bf16: null pointer");
+    PK_REQUIRE(x && grad_out && workspace, "pk_wgrad_bf16: null pointer");
     PK_REQUIRE(M > 0 && N > 0 && Cin > 0 && (ksize == 1 || ksize == 3), "pk_wgrad_bf16: bad sizes");
     PK_SUPPORTED((Cin & 7) == 0 && (N & 7) == 0, "pk_wgrad_bf16: Cin=%d and N=%d must be multiples of 8", Cin, N);
     const bool linear = (Ho == 0);
@@ -733,8 +768,8 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     a.g_scale = g_scale; a.g_rows_per_sample = g_rows_per_sample > 0 ? g_rows_per_sample : 1;
     a.M = M; a.N = N; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = ksize / 2;
     const int S = pk_wgrad_slices(M, N, Cin, a.T);
-    PK_REQUIRE(!dbias || (n_bias > 0 && n_bias <= N), "pk_wgrad_bf16: n_bias");
-    a.bias_part = dbias ? workspace + (size_t)S * N * a.T * Cin : nullptr;     // bias slabs follow the weight slabs
+    PK_REQUIRE(n_bias >= 0 && n_bias <= N && (!dbias || n_bias > 0), "pk_wgrad_bf16: n_bias");
+    a.bias_part = n_bias > 0 ? workspace + (size_t)S * N * a.T * Cin : nullptr;     // bias slabs follow the weight slabs
     a.m_per_slice = ((M + S - 1) / S + WG_MK - 1) / WG_MK * WG_MK;
     const int tl = wgrad_tile(N, Cin);
     a.ctiles = (Cin + tl - 1) / tl;
@@ -742,6 +777,7 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
     if (tl == 128) hipLaunchKernelGGL((k_wgrad2<128, 128>), dim3(((N + 127) / 128) * a.ctiles, a.T, S), dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad2<64, 64>), dim3(((N + 63) / 64) * a.ctiles, a.T, S), dim3(256), 0, st, a);
+    if (!dw) return pk_launch_status("pk_wgrad_bf16");        // slabs only: the caller reduces them later (pk_reduce_many)
     const int total = N * a.T * Cin;
     const int w_blocks = (total + 15) / 16, b_blocks = dbias ? (n_bias + 15) / 16 : 0;
     hipLaunchKernelGGL(k_wgrad_reduce, dim3(w_blocks + b_blocks), dim3(256), 0, st, workspace, dw, S, N, a.T, Cin, out_layout,

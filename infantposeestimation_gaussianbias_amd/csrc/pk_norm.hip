@@ -467,7 +467,7 @@ extern "C" int pk_ln_bwd_blocks(int64_t rows) {
 extern "C" int pk_layernorm_bwd(const void* dy, const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
                                 const void* dresidual, void* dx, float* partial, float* dgamma, float* dbeta, int64_t rows, int C,
                                 int C_real, void* stream) {
-    PK_REQUIRE(dy && x && save_mean && save_rstd && gamma && dx && partial && dgamma && dbeta && rows > 0, "pk_layernorm_bwd: bad argument");
+    PK_REQUIRE(dy && x && save_mean && save_rstd && gamma && dx && partial && rows > 0 && (!dgamma == !dbeta), "pk_layernorm_bwd: bad argument");
     PK_SUPPORTED(C >= 8 && (C & 7) == 0 && C <= 1024, "pk_layernorm_bwd: C=%d", C);
     const int Cr = C_real > 0 ? C_real : C;
     PK_REQUIRE(Cr <= C, "pk_layernorm_bwd: C_real=%d > C=%d", Cr, C);
@@ -488,6 +488,7 @@ extern "C" int pk_layernorm_bwd(const void* dy, const void* x, const float* save
         default: LNB(64, 1); break;
     }
 #undef LNB
+    if (!dgamma) return pk_launch_status("pk_layernorm_bwd");   // partials only: reduced later by pk_reduce_many
     hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, (float*)nullptr, 1.f, 0, dgamma,
                        dbeta, C);
     return pk_launch_status("pk_layernorm_bwd");

@@ -117,6 +117,8 @@ class FlatAdamW:
         self.lr_dev.fill_(lr)
 
     def step(self, grad_scale: float = 1.0):
+        if self.flat.is_cuda:
+            nnops.finalize_deferred()          # postponed parameter-gradient reductions (no-op when the Trainer already ran them)
         if not self._grads_installed:
             self.install_grad_views()
         self.step_count += 1
@@ -303,7 +305,9 @@ class Trainer:
         self.sched = WarmupMultiStepLR(self.opt, t, iters_per_epoch)
         self.comm = GradientExchange(self.opt, bucket_mb, overlap=overlap_comm)
         self.comm.broadcast_initial_state()
-        self.use_graph, self.graph_warmup = use_graph, graph_warmup
+        # >= 2 eager steps before capture: step 1 installs the gradient sinks, step 2 builds the descriptor tables that depend on
+        # them (deferred reductions, padded-twin extraction) -- table uploads are host->device copies and cannot be captured
+        self.use_graph, self.graph_warmup = use_graph, max(2, graph_warmup)
         # autograd binds each AccumulateGrad node to the stream that was current when it was created; warm-up and
         # capture therefore run on ONE dedicated side stream, otherwise backward would sync with the (non-capturing)
         # default stream in the middle of the capture
@@ -321,6 +325,7 @@ class Trainer:
         out["loss"].backward()
         from . import dispatch
         dispatch.join_aux()            # weight-gradient kernels issued on auxiliary streams (dispatch.aux_stream_for)
+        nnops.finalize_deferred()      # ONE launch: all postponed slab reductions of parameter gradients
         tw = getattr(self.model, "_pk_twin", None)
         if tw:
             tw.grads_to_real()         # padded twin: no-op when the end-of-backward callback already extracted the gradients

@@ -196,6 +196,7 @@ class PaddedTwin:
         if not self._pending:
             return
         self._pending = False
+        nnops.finalize_deferred()                # postponed slab reductions write into the twin's gradient buffer first
         used = [k for k, t in self.tp.items() if t._pk_used]
         dst = {}
         for k in used:

@@ -53,6 +53,59 @@ def _up8(n):
     return -(-n // 8) * 8
 
 
+# ================================================================================================ deferred reductions
+# Parameter gradients that go straight into a gradient sink are not read by anything in backward, so their final slab
+# reductions (split-M weight-gradient slabs, LayerNorm dgamma/dbeta partials, rel-pos-bias partials) are not launched where
+# they are produced: the producers write into persistent per-parameter workspaces and register one row per reduction;
+# `finalize_deferred()` (called by whoever consumes the sinks: engine.Trainer / FlatAdamW.step / the padded twin) reduces all
+# of them with ONE pk_reduce_many launch.  ~360 launches per step leave the data-gradient chain.
+_REDUCE_DTYPE = np.dtype([("part", "<i8"), ("out", "<i8"), ("stride", "<i8"), ("S", "<i4"), ("K", "<i4"), ("layout", "<i4"),
+                          ("N", "<i4"), ("T", "<i4"), ("Cin", "<i4"), ("ostride", "<i4"), ("pad", "<i4")])
+_WS = {}                # (sink data_ptr, tag) -> persistent fp32 workspace
+_PENDING = []           # rows registered since the last finalize
+_TABLE = {"key": None}
+
+
+def deferral_enabled():
+    import os
+    return os.environ.get("POSE_DEFER_REDUCE", "1") != "0"
+
+
+def _workspace(sink, tag, numel):
+    key = (sink.data_ptr(), tag)
+    ws = _WS.get(key)
+    if ws is None or ws.numel() < numel or ws.device != sink.device:
+        ws = _WS[key] = torch.empty(numel, dtype=F32, device=sink.device)
+    return ws
+
+
+def _defer(part_ptr, out, slab_stride, S, K, layout=0, N=0, T=1, Cin=1, out_stride=1, out_offset=0):
+    _PENDING.append((part_ptr, out.data_ptr() + 4 * out_offset, slab_stride, S, K, layout, N, T, Cin, out_stride, 0))
+
+
+def finalize_deferred():
+    """Reduce every slab set registered since the last call (no-op when nothing is pending)."""
+    if not _PENDING:
+        return
+    key = tuple(_PENDING)
+    _PENDING.clear()
+    if _TABLE["key"] != key:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.PoseKernelError("deferred-reduction table changed during hipGraph capture (host->device table upload is not "
+                                       "capturable): run at least two eager warm-up steps before capturing")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        desc = np.array(list(key), dtype=_REDUCE_DTYPE)
+        blk_desc, blk_first, nb = [], [], 0
+        for i, r in enumerate(key):
+            k = -(-r[4] // 16)
+            blk_desc += [i] * k
+            blk_first += [nb] * k
+            nb += k
+        _TABLE.update(key=key, desc=torch.from_numpy(desc.view(np.uint8)).to(dev), nb=nb,
+                      blk_desc=torch.tensor(blk_desc, dtype=I32, device=dev), blk_first=torch.tensor(blk_first, dtype=I32, device=dev))
+    call("pk_reduce_many", _TABLE["desc"], _TABLE["blk_desc"], _TABLE["blk_first"], _TABLE["nb"], stream_ptr())
+
+
 # ================================================================================================ weight cache
 _PACK_DTYPE = np.dtype([("src", "<i8"), ("dst_off", "<i8"), ("N", "<i4"), ("C", "<i4"), ("T", "<i4"), ("mode", "<i4"),
                         ("Cp", "<i4"), ("Np", "<i4"), ("dst_numel", "<i8")])
@@ -216,10 +269,22 @@ def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=No
         B, Hs, Ws, Ho, Wo = geom
         M = B * Ho * Wo
     S = _lib.lib.pk_wgrad_slices(M, N, Cin, T)
+    layout = 1 if (geom is not None and oihw) else 0
+    n_bias = 0 if dbias is None else dbias.numel()
+    if deferred and out is not None and deferral_enabled():
+        # slabs into a persistent workspace, reduction postponed to finalize_deferred()
+        ws = _workspace(out, "w", S * N * (T * Cin + 1))
+        call("pk_wgrad_bf16", x, g, ws, None, None, n_bias, a_map, g_map, g_scale, g_rps, M, N, Cin, ksize, stride, B, Hs, Ws, Ho, Wo,
+             layout, stream_ptr())
+        total = N * T * Cin
+        _defer(ws.data_ptr(), out, total, S, total, layout, N, T, Cin)
+        if n_bias:
+            _defer(ws.data_ptr() + 4 * S * total, dbias, N, S, n_bias)
+        return out
     ws = _e((S * N * (T * Cin + 1),), F32, x.device)
     dw = out if out is not None else _e((N, Cin, ksize, ksize) if geom is not None else (N, Cin), F32, x.device)
-    call("pk_wgrad_bf16", x, g, ws, dw, dbias, 0 if dbias is None else dbias.numel(), a_map, g_map, g_scale, g_rps, M, N, Cin, ksize,
-         stride, B, Hs, Ws, Ho, Wo, 1 if (geom is not None and oihw) else 0, stream_ptr())
+    call("pk_wgrad_bf16", x, g, ws, dw, dbias, n_bias, a_map, g_map, g_scale, g_rps, M, N, Cin, ksize,
+         stride, B, Hs, Ws, Ho, Wo, layout, stream_ptr())
     return dw
 
 
@@ -368,10 +433,16 @@ def _layernorm(x2d, gamma, beta, c_real=0):
 def _layernorm_bwd(dy, x2d, mean, rstd, gamma, dres, g_param=None, b_param=None, c_real=0):
     M, C = x2d.shape
     nb = _lib.lib.pk_ln_bwd_blocks(M)
-    part = _e((nb, 2, C), F32, x2d.device)
     dx = _e((M, C), BF16, x2d.device)
     (dg, sg) = _sink(g_param) if g_param is not None else (_e((C,), F32, x2d.device), False)
     (db, sb) = _sink(b_param) if b_param is not None else (_e((C,), F32, x2d.device), False)
+    if sg and sb and deferral_enabled():
+        part = _workspace(dg, "ln", nb * 2 * C)
+        call("pk_layernorm_bwd", dy, x2d, mean, rstd, gamma, dres, dx, part, None, None, M, C, c_real, stream_ptr())
+        _defer(part.data_ptr(), dg, 2 * C, nb, C)
+        _defer(part.data_ptr() + 4 * C, db, 2 * C, nb, C)
+        return dx, None, None
+    part = _e((nb, 2, C), F32, x2d.device)
     call("pk_layernorm_bwd", dy, x2d, mean, rstd, gamma, dres, dx, part, dg, db, M, C, c_real, stream_ptr())
     return dx, (None if sg else dg), (None if sb else db)
 
@@ -427,9 +498,17 @@ class _AttnHalf(torch.autograd.Function):
                         deferred=s_wp and s_bp)
         # attention core
         dqkv = _e((Mw, 3 * C), BF16, dev)
-        part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads),), F32, dev)
         dtable, s_t = _sink(ptab)
-        call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, ctx.pad[1], stream_ptr())
+        n_part = _lib.lib.pk_window_attn_bwd_ws_floats(B * nwin, heads)
+        if s_t and deferral_enabled():
+            part = _workspace(dtable, "rpb", n_part)
+            call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, None, B * nwin, heads, C, ctx.pad[1], stream_ptr())
+            per_head = n_part // 169 // heads
+            for hh in range(heads):      # group g = k*heads + h holds 169 partial sums of head h
+                _defer(part.data_ptr() + 4 * 169 * hh, dtable, 169 * heads, per_head, 169, out_stride=heads, out_offset=hh)
+        else:
+            part = _e((n_part,), F32, dev)
+            call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, dtable, B * nwin, heads, C, ctx.pad[1], stream_ptr())
         # qkv linear: scatter the token gradients back to pixel rows (pad tokens dropped)
         du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
         dst, s_wq = _sink(pwqkv)

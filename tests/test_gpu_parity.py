@@ -580,8 +580,8 @@ def _dp_gpu_worker(rank, world, port, q, use_graph=False):
     tr = engine.Trainer(model, cfg, iters_per_epoch=2, use_graph=use_graph, graph_warmup=1, graph_streams=use_graph)
     init = tr.opt.flat.clone()
     if use_graph:
-        # step 1 eager (warm-up), step 2 captures forward+backward (RCCL/gloo and AdamW stay outside the graph) and replays
-        losses = [float(tr.step(shard)["loss"].detach()) for _ in range(3)]
+        # steps 1-2 eager (warm-up), step 3 captures forward+backward (RCCL/gloo and AdamW stay outside the graph), then replays
+        losses = [float(tr.step(shard)["loss"].detach()) for _ in range(5)]
         torch.cuda.synchronize()
         assert tr._graph is not None and not tr._graph_has_opt
         q.put((rank, init.cpu().numpy(), np.asarray(losses), tr.opt.grad.cpu().numpy(), tr.opt.flat.cpu().numpy(), losses[-1]))
@@ -592,7 +592,8 @@ def _dp_gpu_worker(rank, world, port, q, use_graph=False):
     world_saved, tr.comm.world = tr.comm.world, 1
     tr._fwd_bwd(shard)
     tr.opt.install_grad_views()                              # first backward: adopt autograd's gradients into the flat buffer
-    local = tr.opt.grad.clone()
+    tr._fwd_bwd(shard)                                       # second pass: same kernels as every later step (gradient sinks,
+    local = tr.opt.grad.clone()                              # deferred slab reductions) -> bitwise comparable with the step below
     tr.comm.world = world_saved
     # (the probe pass also advanced the BN running statistics; training-mode gradients do not depend on them)
     out = tr.step(shard)
@@ -629,7 +630,7 @@ def test_trainer_data_parallel_graph_replay_two_ranks_one_gpu():
     assert np.array_equal(i0, i1)
     assert np.array_equal(g0, g1) and np.array_equal(f0, f1)
     assert not np.array_equal(f0, i0)
-    assert np.all(np.isfinite(l0)) and np.all(np.isfinite(l1)) and l0[2] != l0[0]
+    assert np.all(np.isfinite(l0)) and np.all(np.isfinite(l1)) and l0[4] != l0[2] != l0[0]
 
 
 def test_trainer_data_parallel_two_ranks_one_gpu():

@@ -708,27 +708,53 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 // dw/dgamma/dtable == NULL the producers only write their slabs; ONE table-driven launch at the end of backward reduces
 // them all:   out[index(i)] = sum_{s < S} part[s * slab_stride + i],  i < K
 //   layout 0: index(i) = i * out_stride;   layout 1 (conv OIHW): i = (n*T + t)*Cin + c  ->  (n*Cin + c)*T + t.
-// Block = 16 outputs x 16 slab-lanes, fixed-order combine (deterministic).
+// Fixed-order combine (deterministic).
 struct ReduceDesc { const float* part; float* out; int64_t slab_stride; int S, K, layout, N, T, Cin, out_stride, pad_; };
+// Block = 64 outputs (16 groups of 4 consecutive) x 16 slab-lanes: 16-byte loads, 256 contiguous bytes per slab row and block
+// (the first version read 64-byte pieces and ran at a quarter of the HBM rate: 1.17 ms per step for ~1.5 GB of slabs).
 __global__ void __launch_bounds__(256) k_reduce_many(const ReduceDesc* __restrict__ desc, const int* __restrict__ blk_desc,
                                                      const int* __restrict__ blk_first) {
-    __shared__ float sh[16][17];
+    __shared__ float4 sh[16][17];
     const ReduceDesc d = desc[blk_desc[blockIdx.x]];
     const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int i = (blockIdx.x - blk_first[blockIdx.x]) * 16 + col;
-    float s = 0.f;
-    if (i < d.K)
-        for (int k = rl; k < d.S; k += 16) s += d.part[(size_t)k * d.slab_stride + i];
+    const int i = ((blockIdx.x - blk_first[blockIdx.x]) * 16 + col) * 4;
+    const bool vec = ((d.K | (int)d.slab_stride) & 3) == 0 && (((uintptr_t)d.part) & 15) == 0;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < d.K) {
+        if (vec) {
+            for (int k = rl; k < d.S; k += 16) {
+                const float4 v = *reinterpret_cast<const float4*>(d.part + (size_t)k * d.slab_stride + i);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+        } else {
+            for (int k = rl; k < d.S; k += 16) {
+                const float* p = d.part + (size_t)k * d.slab_stride + i;
+                s.x += p[0];
+                if (i + 1 < d.K) s.y += p[1];
+                if (i + 2 < d.K) s.z += p[2];
+                if (i + 3 < d.K) s.w += p[3];
+            }
+        }
+    }
     sh[rl][col] = s;
     __syncthreads();
     if (rl != 0 || i >= d.K) return;
-    s = 0.f;
+    s = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) s += sh[r][col];
-    if (d.layout == 0) d.out[(size_t)i * d.out_stride] = s;
-    else {
-        const int c = i % d.Cin, t = (i / d.Cin) % d.T, n = i / (d.Cin * d.T);
-        d.out[((size_t)n * d.Cin + c) * d.T + t] = s;
+    for (int r = 0; r < 16; ++r) {
+        const float4 v = sh[r][col];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const float o4[4] = {s.x, s.y, s.z, s.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ij = i + j;
+        if (ij >= d.K) break;
+        if (d.layout == 0) d.out[(size_t)ij * d.out_stride] = o4[j];
+        else {
+            const int c = ij % d.Cin, t = (ij / d.Cin) % d.T, n = ij / (d.Cin * d.T);
+            d.out[((size_t)n * d.Cin + c) * d.T + t] = o4[j];
+        }
     }
 }
 extern "C" int pk_reduce_many(const void* desc_table, const int* block_desc, const int* block_first, int n_blocks, void* stream) {

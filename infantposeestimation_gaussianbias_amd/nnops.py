@@ -97,7 +97,7 @@ def finalize_deferred():
         desc = np.array(list(key), dtype=_REDUCE_DTYPE)
         blk_desc, blk_first, nb = [], [], 0
         for i, r in enumerate(key):
-            k = -(-r[4] // 16)
+            k = -(-r[4] // 64)
             blk_desc += [i] * k
             blk_first += [nb] * k
             nb += k

@@ -219,7 +219,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ 
     }
 }
 extern "C" int pk_bn_bwd_blocks(int64_t rows) {
-    int64_t nb = (rows + 255) / 256;
+    // >= 32 rows per block, up to 1024 blocks: the low-resolution branches (3 072 .. 12 288 rows) still get hundreds of
+    // workgroups (rows/256 left them with 12 .. 48 and a 55 us kernel for 3 MB of data)
+    int64_t nb = (rows + 31) / 32;
     return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
 }
 extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* save_mean, const float* save_rstd,
@@ -461,7 +463,7 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const uint4* __restrict__ dy, co
     }
 }
 extern "C" int pk_ln_bwd_blocks(int64_t rows) {
-    int64_t nb = (rows + 511) / 512;
+    int64_t nb = (rows + 31) / 32;             // see pk_bn_bwd_blocks
     return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
 }
 extern "C" int pk_layernorm_bwd(const void* dy, const void* x, const float* save_mean, const float* save_rstd, const float* gamma,

@@ -432,7 +432,14 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     // Shallow contractions (K = T*Cin <= 256: the token-MLP / qkv GEMMs) are bound by their output traffic, not MFMA:
     // 128x64 tiles need half the accumulators (4 waves/SIMD instead of 2) and hide the epilogue's memory latency better
     // (measured 24 vs 32 us for qkv K=32 N=96, 43 vs 51 us for fc1+GELU K=32 N=128, 17 vs 21 us for K=128 N=512).
-    if (a.N > 64 && a.T * a.Cin <= 256 && !a.stats) {
+    // Few pixel rows (low-resolution branches: 24 .. 96 row tiles): a 128-wide N tile leaves most of the 256 CUs idle, so take
+    // the widest N tile that still gives >= 512 workgroups (they are latency-bound, not MFMA-bound, at that size).
+    static const int smallm_on = getenv("PK_IGEMM_SMALLM") ? atoi(getenv("PK_IGEMM_SMALLM")) : 1;
+    const bool small_m = smallm_on && a.N > 64 && (long)gm * ((a.N + 127) / 128) < 512;
+    if (small_m && (long)gm * ((a.N + 63) / 64) < 512 && !a.stats) {
+        if (k64) hipLaunchKernelGGL((k_igemm2<32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<32, 4, 1, 32>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
+    } else if (a.N > 64 && (a.T * a.Cin <= 256 || small_m) && !a.stats) {
         if (k64) hipLaunchKernelGGL((k_igemm2<64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
         else hipLaunchKernelGGL((k_igemm2<64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
     } else if (a.N > 64) {
@@ -767,6 +774,7 @@ static inline int wgrad_tile(int N, int Cin) { return (N >= 128 && Cin >= 128) ?
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
     // enough workgroups to fill 256 CUs several times over (>= 2048), but no slice shorter than 256 rows
     static const int target = getenv("PK_WGRAD_WGS") ? atoi(getenv("PK_WGRAD_WGS")) : 2048;
+    // (shorter slices for the low-resolution branches were measured: 64-row slices cost +1.3 ms per step in slab traffic)
     static const int min_rows = getenv("PK_WGRAD_ROWS") ? atoi(getenv("PK_WGRAD_ROWS")) : 256;
     const int tl = wgrad_tile(N, Cin);
     const int tiles = ((N + tl - 1) / tl) * ((Cin + tl - 1) / tl) * T;

@@ -21,23 +21,25 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
 }
 
 // ================================================================================================ generic partial sums
-// out[k] (+)= scale * sum_b partial[b*stride + k], k < K.  Block = 16 columns x 16 row-lanes: lane r sums rows b = r (mod 16),
-// the 16 lane sums are combined in fixed order -> deterministic, and the serial chain is nb/16 instead of nb.
-__global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ part, int nb, int K, int stride, float* __restrict__ out,
+// out[k] (+)= scale * sum_b partial[b*stride + k], k < K.  Block = 16 columns x 64 row-lanes: lane r sums rows b = r (mod 64),
+// the 64 lane sums are combined in fixed order -> deterministic, and the serial chain is nb/64 instead of nb (these kernels
+// sit between two passes of BatchNorm backward, i.e. on the critical path, with only K/16 workgroups).
+#define RED_LANES 64
+__global__ void __launch_bounds__(16 * RED_LANES) k_sum_partials(const float* __restrict__ part, int nb, int K, int stride, float* __restrict__ out,
                                                       float scale, int accumulate, float* __restrict__ out_lo = nullptr,
                                                       float* __restrict__ out_hi = nullptr, int split = 0) {
-    __shared__ double sh[16][17];
+    __shared__ double sh[RED_LANES][17];
     const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int k = blockIdx.x * 16 + col;
     double s = 0.0;
     if (k < K)
-        for (int b = rl; b < nb; b += 16) s += (double)part[(size_t)b * stride + k];
+        for (int b = rl; b < nb; b += RED_LANES) s += (double)part[(size_t)b * stride + k];
     sh[rl][col] = s;
     __syncthreads();
     if (rl == 0 && k < K) {
         double t = 0.0;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += sh[r][col];
+        for (int r = 0; r < RED_LANES; ++r) t += sh[r][col];
         const float v = (float)t * scale;
         if (out) out[k] = accumulate ? out[k] + v : v;
         if (out_lo && k < split) out_lo[k] = v;            // optional second copy, split into two destinations
@@ -47,27 +49,27 @@ __global__ void __launch_bounds__(256) k_sum_partials(const float* __restrict__ 
 #define SUM_PARTIALS_GRID(K) dim3(((K) + 15) / 16)
 extern "C" int pk_sum_partials(const float* partial, int nb, int K, int stride, float* out, float scale, int accumulate, void* stream) {
     PK_REQUIRE(partial && out && nb > 0 && K > 0 && stride >= K, "pk_sum_partials: bad argument");
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(K), dim3(256), 0, (hipStream_t)stream, partial, nb, K, stride, out, scale, accumulate);
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(K), dim3(16 * RED_LANES), 0, (hipStream_t)stream, partial, nb, K, stride, out, scale, accumulate);
     return pk_launch_status("pk_sum_partials");
 }
 
 // ================================================================================================ BatchNorm (train)
 // Finalize the per-tile column sums written by the conv epilogue: batch mean / biased var -> scale, shift for the
 // apply kernel, saved mean / rstd for backward, running stats (momentum 0.1, UNBIASED var), num_batches_tracked += 1.
-__global__ void __launch_bounds__(256) k_bn_finalize(const float* __restrict__ part, int tiles, int C, float count,
+__global__ void __launch_bounds__(16 * RED_LANES) k_bn_finalize(const float* __restrict__ part, int tiles, int C, float count,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ run_mean, float* __restrict__ run_var,
                                                      long long* __restrict__ nbt, float momentum, float eps,
                                                      float* __restrict__ scale, float* __restrict__ shift,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    // block = 16 channels x 16 tile-lanes; fixed-order combination of the lane sums (deterministic)
-    __shared__ double sh[2][16][17];
+    // block = 16 channels x 64 tile-lanes; fixed-order combination of the lane sums (deterministic)
+    __shared__ double sh[2][RED_LANES][17];
     const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + col;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
     double s = 0.0, q = 0.0;
     if (c < C)
-        for (int t = rl; t < tiles; t += 16) {
+        for (int t = rl; t < tiles; t += RED_LANES) {
             s += (double)part[(size_t)t * 2 * C + c];
             q += (double)part[(size_t)t * 2 * C + C + c];
         }
@@ -77,7 +79,7 @@ __global__ void __launch_bounds__(256) k_bn_finalize(const float* __restrict__ p
     if (rl != 0 || c >= C) return;
     s = 0.0; q = 0.0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < RED_LANES; ++r) {
         s += sh[0][r][col];
         q += sh[1][r][col];
     }
@@ -101,7 +103,7 @@ extern "C" int pk_bn_finalize(const float* stats_partial, int tiles, int C, int 
                               float* scale, float* shift, float* save_mean, float* save_rstd, void* stream) {
     PK_REQUIRE(stats_partial && gamma && beta && scale && shift && save_mean && save_rstd, "pk_bn_finalize: null pointer");
     PK_REQUIRE(tiles > 0 && C > 0 && count > 0, "pk_bn_finalize: bad sizes");
-    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 15) / 16), dim3(256), 0, (hipStream_t)stream, stats_partial, tiles, C, (float)count,
+    hipLaunchKernelGGL(k_bn_finalize, dim3((C + 15) / 16), dim3(16 * RED_LANES), 0, (hipStream_t)stream, stats_partial, tiles, C, (float)count,
                        gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, scale, shift, save_mean,
                        save_rstd);
     return pk_launch_status("pk_bn_finalize");
@@ -237,7 +239,7 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw, save_mean,
                        save_rstd, partial, rows, C, relu, rpb);
     // sums = [sum g | sum g*xhat] for the apply kernel; the same values go to dbeta / dgamma (possibly flat-gradient views)
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0, dbeta, dgamma, C);
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(16 * RED_LANES), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0, dbeta, dgamma, C);
     const size_t chunks = (size_t)rows * (C / 8);
     size_t gb = (chunks + 255) / 256;
     if (gb > 4096) gb = 4096;
@@ -491,7 +493,7 @@ extern "C" int pk_layernorm_bwd(const void* dy, const void* x, const float* save
     }
 #undef LNB
     if (!dgamma) return pk_launch_status("pk_layernorm_bwd");   // partials only: reduced later by pk_reduce_many
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(256), 0, st, partial, nb, 2 * C, 2 * C, (float*)nullptr, 1.f, 0, dgamma,
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(16 * RED_LANES), 0, st, partial, nb, 2 * C, 2 * C, (float*)nullptr, 1.f, 0, dgamma,
                        dbeta, C);
     return pk_launch_status("pk_layernorm_bwd");
 }
@@ -536,7 +538,7 @@ extern "C" int pk_colsum_bf16(const void* g, const int32_t* rowmap, const float*
     const int rpb = (int)((rows + nb - 1) / nb);
     hipLaunchKernelGGL(k_colsum, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint4*)g, rowmap, partial, rows, N, rpb, row_scale,
                        rows_per_sample > 0 ? rows_per_sample : 1);
-    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(N), dim3(256), 0, (hipStream_t)stream, partial, nb, N, N, out, 1.f, 0);
+    hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(N), dim3(16 * RED_LANES), 0, (hipStream_t)stream, partial, nb, N, N, out, 1.f, 0);
     return pk_launch_status("pk_colsum_bf16");
 }
 
@@ -611,14 +613,21 @@ extern "C" int pk_fuse_sum(const void* const* inputs, const int* in_h, const int
 
 // Backward of the bilinear up-sampling (gather form, deterministic): dsrc[b][ys][xs][c] = sum over the output pixels
 // whose taps touch (ys,xs) of weight * dy.  `dy` is the (already relu-masked) gradient at the fused resolution.
+template <int SPLIT>   // lanes that share one output chunk (each takes every SPLIT-th row of the gather window)
 __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dsrc, int B, int H, int W,
                                                       int Hs, int Ws, int C) {
     const int cchunks = C / 8;
     const size_t chunks = (size_t)B * Hs * Ws * cchunks;
     const int ry = (H + Hs - 1) / Hs, rx = (W + Ws - 1) / Ws;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % cchunks);
-        size_t pix = i / cchunks;
+    const int sub = threadIdx.x % SPLIT;
+    const size_t groups_per_grid = (size_t)gridDim.x * blockDim.x / SPLIT;
+    const size_t n_iter = (chunks + groups_per_grid - 1) / groups_per_grid;          // uniform trip count: all lanes reach the shuffles
+    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / SPLIT;
+    for (size_t it = 0; it < n_iter; ++it, i += groups_per_grid) {
+        const bool on = i < chunks;
+        const size_t ii = on ? i : 0;
+        const int cc = (int)(ii % cchunks);
+        size_t pix = ii / cchunks;
         const int xs = (int)(pix % Ws);
         pix /= Ws;
         const int ys = (int)(pix % Hs), b = (int)(pix / Hs);
@@ -628,34 +637,46 @@ __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict
         // (The border clamps only move outputs that are already inside this range.)
         const int oy_lo = max(0, (ys - 1) * ry - 1), oy_hi = min(H, (ys + 2) * ry + 1);
         const int ox_lo = max(0, (xs - 1) * rx - 1), ox_hi = min(W, (xs + 2) * rx + 1);
-        for (int oy = oy_lo; oy < oy_hi; ++oy) {
-            int y0, y1;
-            float fy;
-            bil_taps(oy, Hs, H, y0, y1, fy);
-            const float wy = (y0 == ys ? 1.f - fy : 0.f) + (y1 == ys ? fy : 0.f);
-            if (wy == 0.f) continue;
-            for (int ox = ox_lo; ox < ox_hi; ++ox) {
-                int x0, x1;
-                float fx;
-                bil_taps(ox, Ws, W, x0, x1, fx);
-                const float wx = (x0 == xs ? 1.f - fx : 0.f) + (x1 == xs ? fx : 0.f);
-                if (wx == 0.f) continue;
-                float v[8];
-                unpack8(*reinterpret_cast<const uint4*>(dy + (((size_t)b * H + oy) * W + ox) * C + cc * 8), v);
+        if (on)
+            for (int oy = oy_lo + sub; oy < oy_hi; oy += SPLIT) {
+                int y0, y1;
+                float fy;
+                bil_taps(oy, Hs, H, y0, y1, fy);
+                const float wy = (y0 == ys ? 1.f - fy : 0.f) + (y1 == ys ? fy : 0.f);
+                if (wy == 0.f) continue;
+                for (int ox = ox_lo; ox < ox_hi; ++ox) {
+                    int x0, x1;
+                    float fx;
+                    bil_taps(ox, Ws, W, x0, x1, fx);
+                    const float wx = (x0 == xs ? 1.f - fx : 0.f) + (x1 == xs ? fx : 0.f);
+                    if (wx == 0.f) continue;
+                    float v[8];
+                    unpack8(*reinterpret_cast<const uint4*>(dy + (((size_t)b * H + oy) * W + ox) * C + cc * 8), v);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) acc[j] += wy * wx * v[j];
+                    for (int j = 0; j < 8; ++j) acc[j] += wy * wx * v[j];
+                }
             }
-        }
-        *reinterpret_cast<uint4*>(dsrc + i * 8) = pack8(acc);
+#pragma unroll
+        for (int o = 1; o < SPLIT; o <<= 1)       // fixed butterfly over the SPLIT row-lanes: deterministic
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+        if (on && sub == 0) *reinterpret_cast<uint4*>(dsrc + i * 8) = pack8(acc);
     }
 }
 extern "C" int pk_upsample_bilinear_bwd(const void* dy, void* dsrc, int B, int H, int W, int Hs, int Ws, int C, void* stream) {
     PK_REQUIRE(dy && dsrc && B > 0 && H >= Hs && W >= Ws && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0, "pk_upsample_bilinear_bwd: bad argument");
     const size_t chunks = (size_t)B * Hs * Ws * (C / 8);
-    size_t gb = (chunks + 255) / 256;
+    const int ry = (H + Hs - 1) / Hs;
+    // few output chunks with a tall gather window (scale 4 / 8): spread the window rows over 4 / 16 lanes per chunk
+    const int split = (ry >= 8 && chunks < (1u << 20)) ? 16 : ((ry >= 4 && chunks < (1u << 20)) ? 4 : 1);
+    size_t gb = (chunks * split + 255) / 256;
     if (gb > 4096) gb = 4096;
-    hipLaunchKernelGGL(k_upsample_bwd, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dsrc, B, H, W,
-                       Hs, Ws, C);
+    if (split == 16)
+        hipLaunchKernelGGL(k_upsample_bwd<16>, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dsrc, B, H, W, Hs, Ws, C);
+    else if (split == 4)
+        hipLaunchKernelGGL(k_upsample_bwd<4>, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dsrc, B, H, W, Hs, Ws, C);
+    else
+        hipLaunchKernelGGL(k_upsample_bwd<1>, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)dy, (uint16_t*)dsrc, B, H, W, Hs, Ws, C);
     return pk_launch_status("pk_upsample_bilinear_bwd");
 }
 

@@ -435,6 +435,12 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     // Few pixel rows (low-resolution branches: 24 .. 96 row tiles): a 128-wide N tile leaves most of the 256 CUs idle, so take
     // the widest N tile that still gives >= 512 workgroups (they are latency-bound, not MFMA-bound, at that size).
     static const int smallm_on = getenv("PK_IGEMM_SMALLM") ? atoi(getenv("PK_IGEMM_SMALLM")) : 1;
+    static const int force_bn = getenv("PK_IGEMM_FORCE_BN") ? atoi(getenv("PK_IGEMM_FORCE_BN")) : 0;      // experiment knob
+    if (force_bn == 64 && a.N > 64) {
+        if (k64) hipLaunchKernelGGL((k_igemm2<64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        return pk_launch_status(who);
+    }
     const bool small_m = smallm_on && a.N > 64 && (long)gm * ((a.N + 127) / 128) < 512;
     if (small_m && (long)gm * ((a.N + 63) / 64) < 512 && !a.stats) {
         if (k64) hipLaunchKernelGGL((k_igemm2<32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);

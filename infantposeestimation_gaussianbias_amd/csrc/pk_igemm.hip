@@ -183,7 +183,7 @@ __device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo
 }
 
 template <int BN, int WM, int WN, int BK>
-__global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_igemm2(IgemmArgs p) {
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
     constexpr int CH = BK / 8;                       // 16-byte chunks per tile row
     constexpr int A_PT = BM * CH / 256;              // A chunks per thread (2 or 4)
@@ -276,8 +276,10 @@ __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
             a_voff[i] = off;
         }
     };
-    u32x4 ra[A_PT], rb[B_PT];
-    auto load_tiles = [&](int t, int c0) {       // c0: first channel of this K-chunk (wave-uniform)
+    constexpr bool DEEP = (BN >= 128 && BK == 64);    // global loads issued TWO tiles ahead (second register set), see the main loop
+    constexpr bool FRAG_PREFETCH = !DEEP;             // both together need > 256 registers (occupancy 1: 526 us instead of 352)
+    u32x4 ra[A_PT], rb[B_PT], ra2[DEEP ? A_PT : 1], rb2[DEEP ? B_PT : 1];
+    auto load_tiles = [&](u32x4* ra, u32x4* rb, int t, int c0) {       // c0: first channel of this K-chunk (wave-uniform)
         const bool c_ok = (c0 + kc * 8) < p.Cin;
 #pragma unroll
         for (int i = 0; i < A_PT; ++i)
@@ -286,7 +288,7 @@ __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
         for (int i = 0; i < B_PT; ++i)
             rb[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, c_ok ? b_off[i] : OOB_OFF, (t * p.Cin + c0) * 2, 0);
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](const u32x4* ra, const u32x4* rb, int buf) {
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
             const int row = row0 + RSTEP * i;
@@ -306,43 +308,113 @@ __global__ void __launch_bounds__(256) k_igemm2(IgemmArgs p) {
         for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int t_next = 0, c_next = 0;           // (tap, chunk) of the tile being loaded
-    set_tap(0);
-    load_tiles(0, 0);
-    store_tiles(0);
-    __syncthreads();
+    auto advance = [&]() {                // next (tap, chunk) in contraction order; recomputes the row offsets on a tap change
+        c_next += BK;
+        if (c_next >= p.Cin) {
+            c_next = 0;
+            ++t_next;
+            set_tap(t_next);
+        }
+    };
     const int frow = lane & 15, fkc = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < nk;
-        if (more) {
-            c_next += BK;
-            if (c_next >= p.Cin) {
-                c_next = 0;
-                ++t_next;
-                set_tap(t_next);
+    auto compute = [&](int buf) {
+        if constexpr (BN >= 128 && KS == 2 && FRAG_PREFETCH) {
+            // All fragments of the staged tile are read up front into separate registers (KS x (NI + MI) x 4 VGPRs; the kernel
+            // sits at 2 waves/SIMD either way) and the scheduler is told to interleave the second K-step's LDS reads with the
+            // first K-step's MFMAs: left alone it recycled six fragment registers and exposed an LDS round trip every 4-8 MFMAs.
+            bf16x8 wf[KS][NI], af[KS][MI];
+    #pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+    #pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    const int row = wn * (BN / WN) + a * 16 + frow;
+                    wf[ks][a] = *reinterpret_cast<const bf16x8*>(&sB[buf * BN * BK + row * BK + (((fkc + 4 * ks) ^ swz<BK>(row)) * 8)]);
+                }
+    #pragma unroll
+                for (int b = 0; b < MI; ++b) {
+                    const int row = wm * (BM / WM) + b * 16 + frow;
+                    af[ks][b] = *reinterpret_cast<const bf16x8*>(&sA[buf * BM * BK + row * BK + (((fkc + 4 * ks) ^ swz<BK>(row)) * 8)]);
+                }
             }
-            load_tiles(t_next, c_next);
+    #pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+    #pragma unroll
+                for (int a = 0; a < NI; ++a)
+    #pragma unroll
+                    for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][a], af[ks][b], acc[a][b], 0, 0, 0);
+            if (KS == 2 && NI * MI >= 8) {
+                __builtin_amdgcn_sched_group_barrier(0x100, NI + MI, 0);                 // DS reads: fragments of K-step 0
+    #pragma unroll
+                for (int g = 0; g < (NI + MI) / 2; ++g) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, (NI * MI) / ((NI + MI) / 2), 0);   // a few MFMAs of K-step 0 ...
+                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                              // ... then two reads of K-step 1
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, NI * MI, 0);                 // MFMAs of K-step 1
+            }
+        } else {       // smaller tiles: the extra fragment registers cost a wave of occupancy (measured: slower)
+    #pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                bf16x8 wf[NI], af[MI];
+    #pragma unroll
+                for (int a = 0; a < NI; ++a) {
+                    const int row = wn * (BN / WN) + a * 16 + frow;
+                    wf[a] = *reinterpret_cast<const bf16x8*>(&sB[buf * BN * BK + row * BK + (((fkc + 4 * ks) ^ swz<BK>(row)) * 8)]);
+                }
+    #pragma unroll
+                for (int b = 0; b < MI; ++b) {
+                    const int row = wm * (BM / WM) + b * 16 + frow;
+                    af[b] = *reinterpret_cast<const bf16x8*>(&sA[buf * BM * BK + row * BK + (((fkc + 4 * ks) ^ swz<BK>(row)) * 8)]);
+                }
+    #pragma unroll
+                for (int a = 0; a < NI; ++a)
+    #pragma unroll
+                    for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], af[b], acc[a][b], 0, 0, 0);
+            }
         }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            bf16x8 wf[NI], af[MI];
-#pragma unroll
-            for (int a = 0; a < NI; ++a) {
-                const int row = wn * (BN / WN) + a * 16 + frow;
-                wf[a] = *reinterpret_cast<const bf16x8*>(&sB[buf * BN * BK + row * BK + (((fkc + 4 * ks) ^ swz<BK>(row)) * 8)]);
-            }
-#pragma unroll
-            for (int b = 0; b < MI; ++b) {
-                const int row = wm * (BM / WM) + b * 16 + frow;
-                af[b] = *reinterpret_cast<const bf16x8*>(&sA[buf * BM * BK + row * BK + (((fkc + 4 * ks) ^ swz<BK>(row)) * 8)]);
-            }
-#pragma unroll
-            for (int a = 0; a < NI; ++a)
-#pragma unroll
-                for (int b = 0; b < MI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], af[b], acc[a][b], 0, 0, 0);
-        }
-        if (more) store_tiles(buf ^ 1);
+    };
+    set_tap(0);
+    load_tiles(ra, rb, 0, 0);
+    store_tiles(ra, rb, 0);
+    if constexpr (!DEEP) {
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            const bool more = kt + 1 < nk;
+            if (more) {
+                advance();
+                load_tiles(ra, rb, t_next, c_next);
+            }
+            compute(buf);
+            if (more) store_tiles(ra, rb, buf ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // Prefetch distance 2: while tile kt is multiplied out of LDS, tile kt+1 is already in flight into one register set
+        // and tile kt+2 is requested into the other; a set is written to LDS a full iteration after its loads were issued
+        // (one iteration = 32 MFMAs ~ 0.25 us covers an L2 hit but not an HBM / Infinity-Cache access, and the SQ counters
+        // showed 30 % of the wave cycles parked on s_waitcnt).  Unrolled by two so both sets are indexed statically.
+        if (nk > 1) {
+            advance();
+            load_tiles(ra2, rb2, t_next, c_next);           // tile 1 -> set 2
+        }
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 2 < nk) {
+                advance();
+                load_tiles(ra, rb, t_next, c_next);          // tile kt+2 -> set 1
+            }
+            compute(0);
+            if (kt + 1 < nk) store_tiles(ra2, rb2, 1);       // tile kt+1 (requested one iteration ago) -> LDS buffer 1
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            if (kt + 3 < nk) {
+                advance();
+                load_tiles(ra2, rb2, t_next, c_next);        // tile kt+3 -> set 2
+            }
+            compute(1);
+            if (kt + 2 < nk) store_tiles(ra, rb, 0);         // tile kt+2 -> LDS buffer 0
+            __syncthreads();
+        }
     }
 
     // ---- BatchNorm statistics of the raw fp32 accumulators (rows >= M contribute exact zeros)

@@ -277,7 +277,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         }
     };
     constexpr bool DEEP = (BN >= 128 && BK == 64);    // global loads issued TWO tiles ahead (second register set), see the main loop
-    constexpr bool FRAG_PREFETCH = !DEEP;             // both together need > 256 registers (occupancy 1: 526 us instead of 352)
+    // Fragment double-buffering (below) and the second global-load register set together need > 256 registers (occupancy 1:
+    // head conv 526 us).  Measured one at a time on the 3x3 256->256 head conv (fwd / dgrad): neither 370 / 308 us, fragment
+    // prefetch 352 / 302 us, deep global prefetch 359 / 302 us -- both hide latency, neither removes the ceiling of this
+    // tiling (64x64 wave tiles: 768 LDS cycles per 512 MFMA cycles and K-step).  The deep variant is kept for BK = 64.
+    constexpr bool FRAG_PREFETCH = !DEEP;
     u32x4 ra[A_PT], rb[B_PT], ra2[DEEP ? A_PT : 1], rb2[DEEP ? B_PT : 1];
     auto load_tiles = [&](u32x4* ra, u32x4* rb, int t, int c0) {       // c0: first channel of this K-chunk (wave-uniform)
         const bool c_ok = (c0 + kc * 8) < p.Cin;

@@ -236,6 +236,8 @@ class _Region(torch.autograd.Function):
             for t in graphs[i][1]:
                 t.record_stream(cur)
         ctx.graphs, ctx.side = graphs, side
+        first = {}
+        ctx.same = [first.setdefault(id(t), k) for k, t in enumerate(flat)]     # index of the first occurrence of each input
         return tuple(t.detach() for _, outs in graphs for t in outs)
 
     @staticmethod
@@ -266,6 +268,21 @@ class _Region(torch.autograd.Function):
         for i in range(1, n):
             _order(side[i], cur)
         ctx.graphs = None
+        # An input shared by several callables (exchange unit: every output reads every branch) gets one gradient per use.
+        # Sum them here in ONE launch per input instead of leaving 2-3 elementwise adds per input to the autograd engine.
+        groups = {}
+        for k, f in enumerate(ctx.same):
+            if grads[k] is not None:
+                groups.setdefault(f, []).append(k)
+        for f, ks in groups.items():
+            if len(ks) < 2:
+                continue
+            gs = [grads[k] for k in ks]
+            if len(gs) <= 4 and gs[0].dim() == 4 and gs[0].dtype == nnops.ACT_DTYPE and all(g.shape == gs[0].shape for g in gs):
+                total = nnops.sum_same_shape(gs)
+                for k in ks:
+                    grads[k] = None
+                grads[ks[0]] = total
         return (None, None, *grads)
 
 

@@ -611,6 +611,18 @@ class _FuseSum(torch.autograd.Function):
         return (None, *grads)
 
 
+def sum_same_shape(ts):
+    """Plain sum of 2-4 NHWC bf16 tensors of one shape in ONE launch (no autograd): used for fan-out gradient accumulation."""
+    ts = [t.contiguous() for t in ts]
+    B, H, W, C = ts[0].shape
+    out = _e((B, H, W, C), BF16, ts[0].device)
+    ptrs = torch.tensor([t.data_ptr() for t in ts], dtype=torch.int64)
+    hs = torch.tensor([H] * len(ts), dtype=torch.int32)
+    wsz = torch.tensor([W] * len(ts), dtype=torch.int32)
+    call("pk_fuse_sum", ptrs.data_ptr(), hs.data_ptr(), wsz.data_ptr(), len(ts), out, B, H, W, C, 0, stream_ptr())
+    return out
+
+
 def fuse_sum(xs, relu=True):
     return _FuseSum.apply(relu, *xs)
 

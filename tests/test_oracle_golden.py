@@ -323,6 +323,34 @@ def test_hrformer_small_train_step(golden):
             assert rel_err(P[k[16:]].detach().numpy(), z[k]) < 1e-4, k
 
 
+def test_hrformer_base_eval_and_train_step(golden):
+    """HRFormer-base + fusion head, K=13 (BASELINE cfg 5 at 128x96): the oracle against the reference's fp32 outputs for the
+    configuration whose channels are not multiples of 8 (C = 78, head_dim 39) -- the fixtures the padded-twin GPU tests use."""
+    z, keys, meta = golden("model_base.npz"), golden("state_keys.json"), golden("meta.json")["base"]
+    from recipe import synth_input
+    P = params(keys["hrformer_base_fusion_k13"], 44)
+    with torch.no_grad():
+        o = onet.pose_forward(T(synth_input("base_eval", (1, 3, 128, 96))), P, onet.Ctx())
+    assert rel_err(o["heatmaps"].numpy(), z["base_eval_hm"]) < 1e-4
+    assert rel_err(o["offsets"].numpy()[:, :, :, ::4, ::4], z["base_eval_off"]) < 1e-4
+    kp0, sc0 = odec.fusion_decode(o["heatmaps"].numpy(), o["offsets"].numpy(), float(P["head.subpixel_refine.alpha"]), float(o["fusion_weight"]))
+    assert np.abs(kp0 - z["base_eval_kp"]).max() < 2e-3 and rel_err(sc0, z["base_eval_sc"]) < 1e-4
+    P = {k: v.requires_grad_(v.dtype.is_floating_point) for k, v in params(keys["hrformer_base_fusion_k13"], 44).items()}
+    ctx = onet.Ctx(train=True)
+    o = onet.pose_forward(T(synth_input("base_train", (2, 3, 128, 96))), P, ctx)
+    assert rel_err(o["heatmaps"].detach().numpy(), z["base_train_hm"]) < 1e-4
+    res = olos.fusion_pose_loss(o["heatmaps"], o["offsets"], o["variances"], T(z["base_train_tgt"]), T(z["base_train_w"]),
+                                T(z["base_train_gt"]), (96, 128))
+    got = np.array([float(res[n].detach()) for n in olos.NAMES])
+    assert np.allclose(got, z["base_train_losses"], rtol=1e-4), (got, z["base_train_losses"])
+    res["total_loss"].backward()
+    nograd = sorted(k for k in keys["hrformer_base_fusion_k13#params"] if P[k].grad is None)
+    assert nograd == sorted(meta["base_train_nograd"])
+    for k in z:
+        if k.startswith("base_train_g."):
+            assert rel_err(P[k[13:]].grad.numpy(), z[k]) < 2e-3, k
+
+
 def test_cfg1_hrnet_w18_adamw_trajectory(golden):
     """BASELINE config 1: HRNet(18)+HeatmapHead+KeypointMSELoss, 128x96, B=4, three AdamW steps."""
     z, keys = golden("model_level.npz"), golden("state_keys.json")

@@ -49,7 +49,7 @@ def time_kernel(fn, iters=20, warmup=3):
 
 
 def roofline_of_dominant_kernel(model):
-    """Dominant kernel of the step (rocprof, profiles/): k_igemm2<128,2,2,64> on the fusion head's 3x3 256->256 convs at
+    """Dominant kernel of the step (rocprof, profiles/): k_igemm2<256,128,2,2,32> on the fusion head's 3x3 256->256 convs at
     64x48 (fusion_head.py:215,224,235): 12 launches per step (forward + data-gradient), MFMA-bound.
     Algorithmic flops per launch = 2*M*N*K = 2 * (B*64*48) * 256 * (9*256) = 232 GFLOP at B=64 (3.62 GFLOP/img)."""
     from infantposeestimation_gaussianbias_amd import nnops
@@ -69,7 +69,7 @@ def roofline_of_dominant_kernel(model):
             traffic = round(json.load(f)["traffic_bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": "k_igemm2<128,2,2,64> (head conv3x3 256->256 @64x48, fwd + BN-stat epilogue)", "bound": "mfma",
+    return {"kernel": "k_igemm2<256,128,2,2,32> (head conv3x3 256->256 @64x48, fwd + BN-stat epilogue)", "bound": "mfma",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
             "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss traffic incl. Infinity-Cache hits; algorithmic 202.5e6)",
             "us_per_launch": round(sec * 1e6, 1), "algorithmic_flops": flops}

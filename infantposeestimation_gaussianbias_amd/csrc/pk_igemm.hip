@@ -21,7 +21,7 @@
 typedef __attribute__((ext_vector_type(8))) short bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-#define BM 128
+#define STAT_ROWS 128      // pixel rows per BatchNorm partial-statistics tile (pk_conv_stats_tiles)
 #define BKK 32
 #define LDS_PITCH 40  // bf16 elements per LDS row (32 + 8 pad) = 80 bytes, keeps 16-byte alignment
 
@@ -182,7 +182,7 @@ __device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo
     }
 }
 
-template <int BN, int WM, int WN, int BK>
+template <int BM, int BN, int WM, int WN, int BK>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_igemm2(IgemmArgs p) {
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
     constexpr int CH = BK / 8;                       // 16-byte chunks per tile row
@@ -191,7 +191,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     constexpr int KS = BK / 32;                      // MFMA k-steps per staged tile
     constexpr int TM = BM / WM, TN = BN / WN;        // tile of one wave
     constexpr int EP = TN + 4;                       // fp32 pitch of the epilogue staging tile (conflict-free b128 rows)
-    constexpr int MAIN_HALFS = 2 * BM * BK + 2 * BN * BK, EPI_HALFS = 4 * TM * EP * 2;
+    constexpr int BPP = (MI > 4) ? 2 : MI;           // 16-row accumulator blocks staged per epilogue pass (all of them for BM = 128)
+    constexpr int MAIN_HALFS = 2 * BM * BK + 2 * BN * BK, EPI_HALFS = 4 * (BPP * 16) * EP * 2;
     __shared__ __attribute__((aligned(16))) uint16_t smem[MAIN_HALFS > EPI_HALFS ? MAIN_HALFS : EPI_HALFS];
     uint16_t* sA = smem;                             // [2][BM*BK]
     uint16_t* sB = smem + 2 * BM * BK;               // [2][BN*BK]
@@ -447,52 +448,63 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             }
         }
         __syncthreads();
-        if (tid < BN && n0 + tid < p.N) {
+        constexpr int GROUPS = BM / STAT_ROWS, WPG = WM / GROUPS;        // statistics tiles per workgroup, wave rows per tile
+        static_assert(BM % STAT_ROWS == 0 && WM % GROUPS == 0, "statistics tiles must be whole wave rows");
+        if (tid < BN * GROUPS && n0 + tid % BN < p.N) {
+            const int g = tid / BN, nl = tid % BN;
             float s = 0.f, q = 0.f;
 #pragma unroll
-            for (int w = 0; w < WM; ++w) {
-                s += sStat[(w * BN + tid) * 2];
-                q += sStat[(w * BN + tid) * 2 + 1];
+            for (int w = 0; w < WPG; ++w) {
+                s += sStat[((g * WPG + w) * BN + nl) * 2];
+                q += sStat[((g * WPG + w) * BN + nl) * 2 + 1];
             }
-            float* dst = p.stats + (size_t)mt * 2 * p.N;
-            dst[n0 + tid] = s;
-            dst[p.N + n0 + tid] = q;
+            float* dst = p.stats + (size_t)(mt * GROUPS + g) * 2 * p.N;
+            dst[n0 + nl] = s;
+            dst[p.N + n0 + nl] = q;
         }
     }
 
     // ---- epilogue: accumulators -> wave-private fp32 LDS tile -> rolled loop over 8-column row segments
+    // (BPP 16-row blocks per pass: all of them for BM = 128; two at a time for the 256-row tile, whose 128 x 64 wave tiles
+    // would need 139 KB of staging)
     if (p.stats) __syncthreads();                    // sStat (aliases the staging tile) has been consumed
-    float* stage = reinterpret_cast<float*>(smem) + wave * TM * EP;
-#pragma unroll
-    for (int b = 0; b < MI; ++b)
-#pragma unroll
-        for (int a = 0; a < NI; ++a)
-            *reinterpret_cast<f32x4*>(&stage[(b * 16 + (lane & 15)) * EP + a * 16 + (lane >> 4) * 4]) = acc[a][b];
-    __syncthreads();
+    float* stage = reinterpret_cast<float*>(smem) + wave * (BPP * 16) * EP;
     constexpr int LPR = TN / 8, RPP = 64 / LPR;      // lanes per row, rows per pass
     const int hw_out = p.Ho * p.Wo;
     const int lr = lane / LPR, lc = (lane % LPR) * 8;
     const int n = n0 + wn * TN + lc;
-    if (n >= p.N) return;
+    const bool n_ok = n < p.N;
     f32x4 blo = {0.f, 0.f, 0.f, 0.f}, bhi = {0.f, 0.f, 0.f, 0.f};     // the lane's columns are the same in every pass
-    if (p.bias) {
+    if (p.bias && n_ok) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             if (n + j < p.N) blo[j] = p.bias[n + j];
             if (n + 4 + j < p.N) bhi[j] = p.bias[n + 4 + j];
         }
     }
+#pragma unroll
+    for (int pass = 0; pass < MI / BPP; ++pass) {
+        if (pass) __syncthreads();                   // the previous pass has been read out
+#pragma unroll
+        for (int bb = 0; bb < BPP; ++bb)
+#pragma unroll
+            for (int a = 0; a < NI; ++a)
+                *reinterpret_cast<f32x4*>(&stage[(bb * 16 + (lane & 15)) * EP + a * 16 + (lane >> 4) * 4]) = acc[a][pass * BPP + bb];
+        __syncthreads();
+        if (n_ok) {
 #pragma unroll 2
-    for (int ps = 0; ps < TM / RPP; ++ps) {
-        const int ml = ps * RPP + lr;
-        const int m = m0 + wm * TM + ml;
-        int orow = (m < p.M) ? m : -1;
-        if (orow >= 0 && p.o_rowmap) orow = p.o_rowmap[m];
-        if (orow < 0) continue;
-        const float rs = p.res_scale ? p.res_scale[orow / p.rows_per_sample] : 1.f;
-        const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc]);
-        const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc + 4]);
-        igemm_epilogue_row8(p, lo, hi, blo, bhi, orow, n, rs, hw_out);
+            for (int ps = 0; ps < BPP * 16 / RPP; ++ps) {
+                const int ml = ps * RPP + lr;
+                const int m = m0 + wm * TM + pass * BPP * 16 + ml;
+                int orow = (m < p.M) ? m : -1;
+                if (orow >= 0 && p.o_rowmap) orow = p.o_rowmap[m];
+                if (orow < 0) continue;
+                const float rs = p.res_scale ? p.res_scale[orow / p.rows_per_sample] : 1.f;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc]);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc + 4]);
+                igemm_epilogue_row8(p, lo, hi, blo, bhi, orow, n, rs, hw_out);
+            }
+        }
     }
 }
 
@@ -503,7 +515,16 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     static const int xcd_on = getenv("PK_IGEMM_XCD") ? atoi(getenv("PK_IGEMM_XCD")) : 1;
     a.xcd_remap = xcd_on;
     const dim3 block(256);
-    const unsigned gm = (unsigned)((a.M + BM - 1) / BM);
+    const unsigned gm = (unsigned)((a.M + 127) / 128);
+    // Deep contractions with wide outputs (the 3x3 convs of the head: K = 2304, N = 128/256): 256 x 128 workgroup tile, 128 x 64
+    // per wave -- a third less LDS traffic per MFMA than the 64 x 64 wave tile, which is what bounds those kernels.
+    static const int big_on = getenv("PK_IGEMM_BIG") ? atoi(getenv("PK_IGEMM_BIG")) : 1;
+    // (needs >= 1024 workgroups: with 768 -- N = 128 at M = 196 608 -- the second round of workgroups is half empty and the
+    // kernel is slower than the 128 x 128 tile.  Measured at N = 256: fwd 361 -> 334 us, dgrad 306 -> 285 us.)
+    if (big_on && (a.N % 128) == 0 && a.T * a.Cin >= 576 && (a.Cin % 32) == 0 && (long)((a.M + 255) / 256) * (a.N / 128) >= 1024) {
+        hipLaunchKernelGGL((k_igemm2<256, 128, 2, 2, 32>), dim3((a.M + 255) / 256, a.N / 128), block, 0, st, a);
+        return pk_launch_status(who);
+    }
     const bool k64 = (a.Cin % 64) == 0;              // deeper K-chunks when the channel count allows full 64-wide tiles
     // Shallow contractions (K = T*Cin <= 256: the token-MLP / qkv GEMMs) are bound by their output traffic, not MFMA:
     // 128x64 tiles need half the accumulators (4 waves/SIMD instead of 2) and hide the epilogue's memory latency better
@@ -513,26 +534,26 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     static const int smallm_on = getenv("PK_IGEMM_SMALLM") ? atoi(getenv("PK_IGEMM_SMALLM")) : 1;
     static const int force_bn = getenv("PK_IGEMM_FORCE_BN") ? atoi(getenv("PK_IGEMM_FORCE_BN")) : 0;      // experiment knob
     if (force_bn == 64 && a.N > 64) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
         return pk_launch_status(who);
     }
     const bool small_m = smallm_on && a.N > 64 && (long)gm * ((a.N + 127) / 128) < 512;
     if (small_m && (long)gm * ((a.N + 63) / 64) < 512 && !a.stats) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<32, 4, 1, 32>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 32>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
     } else if (a.N > 64 && (a.T * a.Cin <= 256 || small_m) && !a.stats) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
     } else if (a.N > 64) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<128, 2, 2, 64>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<128, 2, 2, 32>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<128, 128, 2, 2, 64>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<128, 128, 2, 2, 32>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
     } else if (a.N > 32) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<64, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<64, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
     } else {
-        if (k64) hipLaunchKernelGGL((k_igemm2<32, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<32, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
+        if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
+        else hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
     }
     return pk_launch_status(who);
 }
@@ -579,7 +600,7 @@ extern "C" int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, fl
     return igemm_launch(a, (hipStream_t)stream, "pk_conv2d_nhwc");
 }
 
-extern "C" int pk_conv_stats_tiles(int M) { return (M + BM - 1) / BM; }
+extern "C" int pk_conv_stats_tiles(int M) { return (M + STAT_ROWS - 1) / STAT_ROWS; }
 
 extern "C" int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, const void* residual,
                               const float* res_scale, const int32_t* a_rowmap, const int32_t* o_rowmap, void* preact_out,

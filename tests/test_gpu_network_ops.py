@@ -65,7 +65,10 @@ class Holder(torch.nn.Module):
 # ------------------------------------------------------------------------------------------------ conv kernel
 @pytest.mark.parametrize("B,H,W,Cin,Cout,k,s", [(2, 9, 7, 16, 24, 3, 1), (2, 10, 6, 8, 16, 3, 2), (1, 5, 5, 32, 40, 1, 1),
                                                 (3, 11, 13, 40, 136, 3, 1), (2, 7, 9, 24, 32, 3, 2), (4, 64, 48, 32, 256, 3, 1),
-                                                (1, 16, 12, 256, 128, 3, 1), (2, 8, 6, 64, 32, 1, 1)])
+                                                (1, 16, 12, 256, 128, 3, 1), (2, 8, 6, 64, 32, 1, 1),
+                                                # M = 67 200 >= 65 536 with a half-filled last 256-row tile: the 256 x 128 workgroup
+                                                # tile (K >= 576, N % 128 == 0) for forward, and for dgrad in the second case
+                                                (6, 112, 100, 64, 128, 3, 1), (5, 120, 112, 128, 256, 3, 1)])
 def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
     from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
     conv = torch.nn.Conv2d(Cin, Cout, k, s, k // 2, bias=False)

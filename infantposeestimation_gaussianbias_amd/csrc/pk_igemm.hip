@@ -873,14 +873,23 @@ extern "C" int pk_reduce_many(const void* desc_table, const int* block_desc, con
     return pk_launch_status("pk_reduce_many");
 }
 
-static inline int wgrad_tile(int N, int Cin) { return (N >= 128 && Cin >= 128) ? 128 : 64; }
+// Output tile (TN x TC): 64 x 64 or 128 x 128.  A 256 x 128 tile (128 x 64 per wave, as in k_igemm2) exists behind
+// PK_WGRAD_BIG=1 but is SLOWER here (head conv 716 us vs 523 us): the weight-gradient kernel is bound by its global loads
+// (46 % of the wave cycles parked on s_waitcnt), and the larger tile drops it from 3 to 2 waves per SIMD.
+static inline void wgrad_tile2(int N, int Cin, int T, int& tn, int& tc) {
+    static const int big_on = getenv("PK_WGRAD_BIG") ? atoi(getenv("PK_WGRAD_BIG")) : 0;
+    if (big_on && T == 9 && (N % 256) == 0 && (Cin % 128) == 0) { tn = 256; tc = 128; }
+    else if (N >= 128 && Cin >= 128) tn = tc = 128;
+    else tn = tc = 64;
+}
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
     // enough workgroups to fill 256 CUs several times over (>= 2048), but no slice shorter than 256 rows
     static const int target = getenv("PK_WGRAD_WGS") ? atoi(getenv("PK_WGRAD_WGS")) : 2048;
     // (shorter slices for the low-resolution branches were measured: 64-row slices cost +1.3 ms per step in slab traffic)
     static const int min_rows = getenv("PK_WGRAD_ROWS") ? atoi(getenv("PK_WGRAD_ROWS")) : 256;
-    const int tl = wgrad_tile(N, Cin);
-    const int tiles = ((N + tl - 1) / tl) * ((Cin + tl - 1) / tl) * T;
+    int tn, tc;
+    wgrad_tile2(N, Cin, T, tn, tc);
+    const int tiles = ((N + tn - 1) / tn) * ((Cin + tc - 1) / tc) * T;
     int s = (target + tiles - 1) / tiles;
     const int max_s = (M + min_rows - 1) / min_rows;
     if (s > max_s) s = max_s;
@@ -908,12 +917,15 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     PK_REQUIRE(n_bias >= 0 && n_bias <= N && (!dbias || n_bias > 0), "pk_wgrad_bf16: n_bias");
     a.bias_part = n_bias > 0 ? workspace + (size_t)S * N * a.T * Cin : nullptr;     // bias slabs follow the weight slabs
     a.m_per_slice = ((M + S - 1) / S + WG_MK - 1) / WG_MK * WG_MK;
-    const int tl = wgrad_tile(N, Cin);
-    a.ctiles = (Cin + tl - 1) / tl;
+    int tn, tc;
+    wgrad_tile2(N, Cin, a.T, tn, tc);
+    a.ctiles = (Cin + tc - 1) / tc;
     hipStream_t st = (hipStream_t)stream;
     PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
-    if (tl == 128) hipLaunchKernelGGL((k_wgrad2<128, 128>), dim3(((N + 127) / 128) * a.ctiles, a.T, S), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad2<64, 64>), dim3(((N + 63) / 64) * a.ctiles, a.T, S), dim3(256), 0, st, a);
+    const dim3 grid(((N + tn - 1) / tn) * a.ctiles, a.T, S);
+    if (tn == 256) hipLaunchKernelGGL((k_wgrad2<256, 128>), grid, dim3(256), 0, st, a);
+    else if (tn == 128) hipLaunchKernelGGL((k_wgrad2<128, 128>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad2<64, 64>), grid, dim3(256), 0, st, a);
     if (!dw) return pk_launch_status("pk_wgrad_bf16");        // slabs only: the caller reduces them later (pk_reduce_many)
     const int total = N * a.T * Cin;
     const int w_blocks = (total + 15) / 16, b_blocks = dbias ? (n_bias + 15) / 16 : 0;

@@ -678,7 +678,12 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
 #pragma unroll
     for (int i = 0; i < X_PT; ++i) { const int q = tid + 256 * i; x_row[i] = q / XCH; x_col[i] = (q % XCH) * 8; }
 
+    // The DropPath row scale is applied when the staged registers are written to LDS, not when they are loaded: scaling at
+    // load time consumed the load result immediately and serialised every step of the proj / fc2 weight gradients on a
+    // global-memory round trip.  (Tried and dropped: a second register set with loads two steps ahead -- the duplicated loop
+    // body pushed the 128 x 128 tile into scratch, 523 -> 1 816 us, and bought nothing on the 64 x 64 tile.)
     u32x4 rgv[G_PT], rxv[X_PT];
+    float rsc[G_PT];
     auto load = [&](int ms) {
 #pragma unroll
         for (int i = 0; i < G_PT; ++i) {
@@ -693,11 +698,7 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
                 }
             }
             rgv[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
-            if (p.g_scale) {
-                uint16_t* e = reinterpret_cast<uint16_t*>(&rgv[i]);
-#pragma unroll
-                for (int j = 0; j < 8; ++j) e[j] = f32_to_bf16(bf16_to_f32(e[j]) * sc);
-            }
+            rsc[i] = sc;
         }
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) {
@@ -718,7 +719,16 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
     };
     auto store = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < G_PT; ++i) *reinterpret_cast<u32x4*>(&sG[buf][g_row[i] * PN + g_col[i]]) = rgv[i];
+        for (int i = 0; i < G_PT; ++i) {
+            u32x4 v = rgv[i];
+            if (p.g_scale) {
+                const float sc = rsc[i];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    v[j] = pack_bf16x2(__uint_as_float(v[j] << 16) * sc, __uint_as_float(v[j] & 0xffff0000u) * sc);
+            }
+            *reinterpret_cast<u32x4*>(&sG[buf][g_row[i] * PN + g_col[i]]) = v;
+        }
 #pragma unroll
         for (int i = 0; i < X_PT; ++i) *reinterpret_cast<u32x4*>(&sX[buf][x_row[i] * PC + x_col[i]]) = rxv[i];
     };

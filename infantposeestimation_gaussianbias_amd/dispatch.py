@@ -161,8 +161,13 @@ _AUX = {}
 _AUX_DIRTY = {}
 
 
+def aux_wgrad_mode() -> int:
+    """0 = off (default), 1 = every sink-bound weight gradient, 2 = only the large 3x3 convs (the head)."""
+    return int(os.environ.get("POSE_AUX_WGRAD", "0")) if streams_enabled() else 0
+
+
 def aux_wgrad_enabled() -> bool:
-    return streams_enabled() and os.environ.get("POSE_AUX_WGRAD", "0") == "1"
+    return aux_wgrad_mode() > 0
 
 
 def aux_stream_for(cur, inputs):

@@ -652,14 +652,14 @@ __device__ __forceinline__ bf16x8 tr_frag(const uint16_t* tile, int pitch, int c
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 
-template <int TN, int TC>   // output tile: TN rows (n) x TC columns (c); 4 waves as 2 x 2
-__global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
+template <int TN, int TC, int MK>   // output tile: TN rows (n) x TC columns (c), 4 waves as 2 x 2; MK pixel rows staged per step
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 128 && MK == 32 ? 4 : 1))) k_wgrad2(WgradArgs p) {
     constexpr int PN = TN + 16, PC = TC + 16;            // LDS row pitches (elements)
     constexpr int GCH = TN / 8, XCH = TC / 8;            // 16-byte chunks per staged row
-    constexpr int G_PT = WG_MK * GCH / 256, X_PT = WG_MK * XCH / 256;   // chunks per thread per step (1 or 2)
+    constexpr int G_PT = MK * GCH / 256, X_PT = MK * XCH / 256;   // chunks per thread per step (1 or 2)
     constexpr int NI = TN / 2 / 16, CI = TC / 2 / 16;    // accumulator tiles per wave
-    __shared__ __attribute__((aligned(16))) uint16_t sG[2][WG_MK * PN];
-    __shared__ __attribute__((aligned(16))) uint16_t sX[2][WG_MK * PC];
+    __shared__ __attribute__((aligned(16))) uint16_t sG[2][MK * PN];
+    __shared__ __attribute__((aligned(16))) uint16_t sX[2][MK * PC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntile = blockIdx.x / p.ctiles, ctile = blockIdx.x - ntile * p.ctiles;
     const int n0 = ntile * TN, c0 = ctile * TC, t = blockIdx.y;
@@ -738,7 +738,7 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
 #pragma unroll
         for (int b = 0; b < CI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
     const int wn = wave >> 1, wc = wave & 1;
-    const int nsteps = (m_end - m_begin + WG_MK - 1) / WG_MK;
+    const int nsteps = (m_end - m_begin + MK - 1) / MK;
     const bool do_bias = p.bias_part && ctile == 0 && t == 0;      // one workgroup column per n-tile owns the bias slab
     float bsum = 0.f;
     if (nsteps > 0) {
@@ -748,20 +748,23 @@ __global__ void __launch_bounds__(256) k_wgrad2(WgradArgs p) {
     __syncthreads();
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) load(m_begin + (s + 1) * WG_MK);
+        if (s + 1 < nsteps) load(m_begin + (s + 1) * MK);
         if (do_bias && tid < TN) {          // column tid of the staged G tile: 32 rows, fixed order
 #pragma unroll 8
-            for (int r = 0; r < WG_MK; ++r) bsum += bf16_to_f32(sG[buf][r * PN + tid]);
+            for (int r = 0; r < MK; ++r) bsum += bf16_to_f32(sG[buf][r * PN + tid]);
         }
-        bf16x8 gf[NI], xf[CI];
 #pragma unroll
-        for (int a = 0; a < NI; ++a) gf[a] = tr_frag(sG[buf], PN, wn * (TN / 2) + a * 16, lane);
+        for (int ks = 0; ks < MK / 32; ++ks) {
+            bf16x8 gf[NI], xf[CI];
 #pragma unroll
-        for (int b = 0; b < CI; ++b) xf[b] = tr_frag(sX[buf], PC, wc * (TC / 2) + b * 16, lane);
+            for (int a = 0; a < NI; ++a) gf[a] = tr_frag(sG[buf] + 32 * ks * PN, PN, wn * (TN / 2) + a * 16, lane);
 #pragma unroll
-        for (int a = 0; a < NI; ++a)
+            for (int b = 0; b < CI; ++b) xf[b] = tr_frag(sX[buf] + 32 * ks * PC, PC, wc * (TC / 2) + b * 16, lane);
 #pragma unroll
-            for (int b = 0; b < CI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
+            for (int a = 0; a < NI; ++a)
+#pragma unroll
+                for (int b = 0; b < CI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
+        }
         if (s + 1 < nsteps) store(buf ^ 1);
         __syncthreads();
     }
@@ -926,16 +929,19 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     const int S = pk_wgrad_slices(M, N, Cin, a.T);
     PK_REQUIRE(n_bias >= 0 && n_bias <= N && (!dbias || n_bias > 0), "pk_wgrad_bf16: n_bias");
     a.bias_part = n_bias > 0 ? workspace + (size_t)S * N * a.T * Cin : nullptr;     // bias slabs follow the weight slabs
-    a.m_per_slice = ((M + S - 1) / S + WG_MK - 1) / WG_MK * WG_MK;
+    a.m_per_slice = ((M + S - 1) / S + 63) / 64 * 64;
     int tn, tc;
     wgrad_tile2(N, Cin, a.T, tn, tc);
     a.ctiles = (Cin + tc - 1) / tc;
     hipStream_t st = (hipStream_t)stream;
     PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
     const dim3 grid(((N + tn - 1) / tn) * a.ctiles, a.T, S);
-    if (tn == 256) hipLaunchKernelGGL((k_wgrad2<256, 128>), grid, dim3(256), 0, st, a);
-    else if (tn == 128) hipLaunchKernelGGL((k_wgrad2<128, 128>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad2<64, 64>), grid, dim3(256), 0, st, a);
+    static const int mk64 = getenv("PK_WGRAD_MK64") ? atoi(getenv("PK_WGRAD_MK64")) : 0;       // experiment: 64 rows per step
+    if (tn == 256) hipLaunchKernelGGL((k_wgrad2<256, 128, 32>), grid, dim3(256), 0, st, a);
+    else if (tn == 128 && (mk64 & 1)) hipLaunchKernelGGL((k_wgrad2<128, 128, 64>), grid, dim3(256), 0, st, a);
+    else if (tn == 128) hipLaunchKernelGGL((k_wgrad2<128, 128, 32>), grid, dim3(256), 0, st, a);
+    else if (mk64 & 2) hipLaunchKernelGGL((k_wgrad2<64, 64, 64>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad2<64, 64, 32>), grid, dim3(256), 0, st, a);
     if (!dw) return pk_launch_status("pk_wgrad_bf16");        // slabs only: the caller reduces them later (pk_reduce_many)
     const int total = N * a.T * Cin;
     const int w_blocks = (total + 15) / 16, b_blocks = dbias ? (n_bias + 15) / 16 : 0;

@@ -536,6 +536,35 @@ def test_region_mode_gradients_match_stream_mode():
     assert float((a - b).norm() / a.norm()) < 2e-2           # bf16 re-association of fan-out gradient sums only
 
 
+def test_deferred_reductions_match_inline_reductions(monkeypatch):
+    """Parameter gradients with the slab reductions postponed to ONE pk_reduce_many launch equal the ones produced by the
+    per-layer reduce kernels (same slabs; only LayerNorm / rel-pos-bias sums use a different fixed summation tree)."""
+    from infantposeestimation_gaussianbias_amd import engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    batch = synthetic_batch(2, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=21)
+    grads = {}
+    for defer in ("0", "1"):
+        monkeypatch.setenv("POSE_DEFER_REDUCE", defer)
+        torch.manual_seed(0)
+        model = build_model(cfg).to(DEV)
+        model.backbone.drop_path_rate = 0.0
+        tr = engine.Trainer(model, cfg, iters_per_epoch=2)
+        tr._fwd_bwd(batch)
+        tr.opt.install_grad_views()           # gradient sinks from here on
+        tr._fwd_bwd(batch)
+        torch.cuda.synchronize()
+        grads[defer] = tr.opt.grad.clone()
+    a, b = grads["0"], grads["1"]
+    assert float((a - b).abs().max() / a.abs().max()) < 1e-6
+    names = [n for n, p, o in zip(tr.opt.names, tr.opt.params, tr.opt.offsets)
+             if not torch.equal(a[o:o + p.numel()], b[o:o + p.numel()])]
+    assert all(("norm" in n) or ("relative_position_bias_table" in n) for n in names), names[:5]   # weight/bias gradients: bit-identical
+
+
 def test_graph_with_branch_streams_matches_eager_steps():
     """hipGraph capture WITH concurrent branch streams (region-mode fork/join) follows the loss trajectory of the same
     autograd structure launched eagerly."""

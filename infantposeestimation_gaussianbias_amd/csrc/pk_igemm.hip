@@ -531,13 +531,8 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     // (measured 24 vs 32 us for qkv K=32 N=96, 43 vs 51 us for fc1+GELU K=32 N=128, 17 vs 21 us for K=128 N=512).
     // Few pixel rows (low-resolution branches: 24 .. 96 row tiles): a 128-wide N tile leaves most of the 256 CUs idle, so take
     // the widest N tile that still gives >= 512 workgroups (they are latency-bound, not MFMA-bound, at that size).
+    // (128 x 64 tiles for the large convs were measured too: head conv 421 us instead of 361 us.)
     static const int smallm_on = getenv("PK_IGEMM_SMALLM") ? atoi(getenv("PK_IGEMM_SMALLM")) : 1;
-    static const int force_bn = getenv("PK_IGEMM_FORCE_BN") ? atoi(getenv("PK_IGEMM_FORCE_BN")) : 0;      // experiment knob
-    if (force_bn == 64 && a.N > 64) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
-        return pk_launch_status(who);
-    }
     const bool small_m = smallm_on && a.N > 64 && (long)gm * ((a.N + 127) / 128) < 512;
     if (small_m && (long)gm * ((a.N + 63) / 64) < 512 && !a.stats) {
         if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
@@ -886,13 +881,13 @@ extern "C" int pk_reduce_many(const void* desc_table, const int* block_desc, con
     return pk_launch_status("pk_reduce_many");
 }
 
-// Output tile (TN x TC): 64 x 64 or 128 x 128.  A 256 x 128 tile (128 x 64 per wave, as in k_igemm2) exists behind
-// PK_WGRAD_BIG=1 but is SLOWER here (head conv 716 us vs 523 us): the weight-gradient kernel is bound by its global loads
-// (46 % of the wave cycles parked on s_waitcnt), and the larger tile drops it from 3 to 2 waves per SIMD.
+// Output tile (TN x TC): 64 x 64 or 128 x 128.  Measured and dropped: a 256 x 128 tile (128 x 64 per wave, as in k_igemm2)
+// is slower here (head conv 716 us vs 523 us) -- the weight-gradient kernel is bound by its global loads (46 % of the wave
+// cycles parked on s_waitcnt) and the larger tile drops it from 3 to 2 waves per SIMD; 64 pixel rows per step instead of 32
+// (more bytes in flight, half the barriers) costs occupancy as well: 734 us on the 128 tile, +0.4 ms per step on the 64 tile.
+// What did help the 128 tile: all-VGPR accumulators at 4 waves per SIMD (527 -> 492 us).
 static inline void wgrad_tile2(int N, int Cin, int T, int& tn, int& tc) {
-    static const int big_on = getenv("PK_WGRAD_BIG") ? atoi(getenv("PK_WGRAD_BIG")) : 0;
-    if (big_on && T == 9 && (N % 256) == 0 && (Cin % 128) == 0) { tn = 256; tc = 128; }
-    else if (N >= 128 && Cin >= 128) tn = tc = 128;
+    if (N >= 128 && Cin >= 128) tn = tc = 128;
     else tn = tc = 64;
 }
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
@@ -936,11 +931,7 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     hipStream_t st = (hipStream_t)stream;
     PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
     const dim3 grid(((N + tn - 1) / tn) * a.ctiles, a.T, S);
-    static const int mk64 = getenv("PK_WGRAD_MK64") ? atoi(getenv("PK_WGRAD_MK64")) : 0;       // experiment: 64 rows per step
-    if (tn == 256) hipLaunchKernelGGL((k_wgrad2<256, 128, 32>), grid, dim3(256), 0, st, a);
-    else if (tn == 128 && (mk64 & 1)) hipLaunchKernelGGL((k_wgrad2<128, 128, 64>), grid, dim3(256), 0, st, a);
-    else if (tn == 128) hipLaunchKernelGGL((k_wgrad2<128, 128, 32>), grid, dim3(256), 0, st, a);
-    else if (mk64 & 2) hipLaunchKernelGGL((k_wgrad2<64, 64, 64>), grid, dim3(256), 0, st, a);
+    if (tn == 128) hipLaunchKernelGGL((k_wgrad2<128, 128, 32>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((k_wgrad2<64, 64, 32>), grid, dim3(256), 0, st, a);
     if (!dw) return pk_launch_status("pk_wgrad_bf16");        // slabs only: the caller reduces them later (pk_reduce_many)
     const int total = N * a.T * Cin;

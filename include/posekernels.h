@@ -97,6 +97,9 @@ int pk_pixel_loss_bwd(const float* pred, const float* target, const float* weigh
                       float* d_pred, int B, int K, int HW, int kind, void* stream);
 /* MorphologyShapeLoss statistics (models/losses.py:69-104): mean (BK,2), variance (BK,2) of hm/(sum+1e-8) */
 int pk_spatial_stats(const float* heatmaps, float* mean, float* var, int BK, int H, int W, void* stream);
+/* backward of pk_spatial_stats (MorphologyShapeLoss, models/losses.py:50-135): grad_mean / grad_var (BK,2) -> grad_heatmaps */
+int pk_spatial_stats_bwd(const float* heatmaps, const float* mean, const float* var, const float* grad_mean, const float* grad_var,
+                         float* grad_heatmaps, int BK, int H, int W, void* stream);
 
 /* ---- S1: AdamW on one flat fp32 buffer (train.py:55-97 grouping; torch.optim.AdamW arithmetic) -----------
  * decay_mask: 1 byte per element (1 = apply weight decay).  lr/step come from DEVICE scalars so a captured

@@ -376,3 +376,35 @@ extern "C" int pk_spatial_stats(const float* heatmaps, float* mean, float* var, 
     hipLaunchKernelGGL(k_spatial_stats, dim3(BK), dim3(256), 0, (hipStream_t)stream, heatmaps, mean, var, H, W);
     return pk_launch_status("pk_spatial_stats");
 }
+
+// Backward of k_spatial_stats.  With S = sum h, inv = 1/(S + 1e-8), p = h*inv, q = S*inv:
+//   d mean_x / d h_j = inv * (x_j - m_x)
+//   d var_x  / d h_j = inv * ((x_j - m_x)^2 - v_x - 2 (x_j - m_x) m_x (1 - q))      (the last term is the 1e-8 in the normaliser)
+// and the same along y.  One block per map: recompute S, then one pass over the pixels.
+__global__ void __launch_bounds__(256) k_spatial_stats_bwd(const float* __restrict__ hm, const float* __restrict__ mean,
+                                                           const float* __restrict__ var, const float* __restrict__ gmean,
+                                                           const float* __restrict__ gvar, float* __restrict__ dhm, int H, int W) {
+    __shared__ float red[16];
+    const int map = blockIdx.x, n = H * W;
+    const float* h = hm + (size_t)map * n;
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += h[i];
+    s = block_sum(s, red);
+    const float inv = 1.f / (s + EPS8), q = s * inv;
+    const float mx = mean[2 * map], my = mean[2 * map + 1], vx = var[2 * map], vy = var[2 * map + 1];
+    const float gmx = gmean[2 * map], gmy = gmean[2 * map + 1], gvx = gvar[2 * map], gvy = gvar[2 * map + 1];
+    const float cx = 2.f * mx * (1.f - q), cy = 2.f * my * (1.f - q);
+    float* d = dhm + (size_t)map * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / W;
+        const float dx = (float)(i - y * W) - mx, dy = (float)y - my;
+        d[i] = inv * (gmx * dx + gmy * dy + gvx * (dx * dx - vx - cx * dx) + gvy * (dy * dy - vy - cy * dy));
+    }
+}
+extern "C" int pk_spatial_stats_bwd(const float* heatmaps, const float* mean, const float* var, const float* grad_mean,
+                                    const float* grad_var, float* grad_heatmaps, int BK, int H, int W, void* stream) {
+    PK_REQUIRE(heatmaps && mean && var && grad_mean && grad_var && grad_heatmaps && BK > 0 && H > 0 && W > 0, "pk_spatial_stats_bwd: bad argument");
+    hipLaunchKernelGGL(k_spatial_stats_bwd, dim3(BK), dim3(256), 0, (hipStream_t)stream, heatmaps, mean, var, grad_mean, grad_var,
+                       grad_heatmaps, H, W);
+    return pk_launch_status("pk_spatial_stats_bwd");
+}

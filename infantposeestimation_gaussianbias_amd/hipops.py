@@ -191,13 +191,31 @@ def pixel_loss(pred, target, weight, kind):
     return _PixelLoss.apply(pred, target, weight, int(kind))
 
 
+class _SpatialStats(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, hm):
+        hm = _chk(hm)
+        B, K, H, W = hm.shape
+        mean = torch.empty(B, K, 2, dtype=F32, device=hm.device)
+        var = torch.empty(B, K, 2, dtype=F32, device=hm.device)
+        call("pk_spatial_stats", hm, mean, var, B * K, H, W, stream_ptr())
+        ctx.save_for_backward(hm, mean, var)
+        return mean, var
+
+    @staticmethod
+    def backward(ctx, gmean, gvar):
+        hm, mean, var = ctx.saved_tensors
+        B, K, H, W = hm.shape
+        gmean = torch.zeros_like(mean) if gmean is None else gmean.contiguous().float()
+        gvar = torch.zeros_like(var) if gvar is None else gvar.contiguous().float()
+        dhm = torch.empty_like(hm)
+        call("pk_spatial_stats_bwd", hm, mean, var, gmean, gvar, dhm, B * K, H, W, stream_ptr())
+        return dhm
+
+
 def spatial_stats(hm):
-    hm = _chk(hm)
-    B, K, H, W = hm.shape
-    mean = torch.empty(B, K, 2, dtype=F32, device=hm.device)
-    var = torch.empty(B, K, 2, dtype=F32, device=hm.device)
-    call("pk_spatial_stats", hm, mean, var, B * K, H, W, stream_ptr())
-    return mean, var
+    """centre of mass and per-axis variance of hm/(sum+1e-8): (B,K,2), (B,K,2); differentiable w.r.t. hm."""
+    return _SpatialStats.apply(hm)
 
 
 # ------------------------------------------------------------------------------------------------ optimiser

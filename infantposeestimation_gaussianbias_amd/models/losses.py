@@ -19,8 +19,8 @@ class FusedPoseLoss(nn.Module):
 
 class MorphologyShapeLoss(nn.Module):
     """lambda_var*MSE(var) + lambda_mean*MSE(mean) of hm/(sum+1e-8), weighted, mean (losses.py:50-135).
-    Statistics come from one reduction kernel per tensor; inference-time value only (no backward kernel yet:
-    the class has no importer in the reference and is not on the training path)."""
+    Statistics come from one reduction kernel per tensor (pk_spatial_stats) with a matching backward kernel; the few-hundred
+    element combination of the statistics is torch elementwise on the device."""
 
     def __init__(self, lambda_variance=1.0, lambda_mean=0.5):
         super().__init__()
@@ -29,10 +29,10 @@ class MorphologyShapeLoss(nn.Module):
     def compute_spatial_statistics(self, heatmaps):
         return hipops.spatial_stats(heatmaps.float())
 
-    @torch.no_grad()
     def forward(self, pred_heatmaps, target_heatmaps, target_weight=None):
         pm, pv = self.compute_spatial_statistics(pred_heatmaps)
-        tm, tv = self.compute_spatial_statistics(target_heatmaps)
+        with torch.no_grad():
+            tm, tv = self.compute_spatial_statistics(target_heatmaps)
         e = self.lambda_variance * (pv - tv) ** 2 + self.lambda_mean * (pm - tm) ** 2
         if target_weight is not None:
             e = e * target_weight.view(e.shape[0], e.shape[1], 1)

@@ -216,6 +216,13 @@ def test_named_losses_vs_golden(golden, tag):
                                 {"heatmaps": tgt, "coords": b, "weights": w})
     got = np.array([float(tot)] + [float(d[k]) for k in ("heatmap", "morph", "regression", "refined")])
     assert np.allclose(got, z[f"{tag}_l4_combined"], rtol=2e-4)
+    # MorphologyShapeLoss backward (pk_spatial_stats_bwd) against autograd through the CPU oracle of the same formula
+    from oracle import losses as olos
+    hr = torch.relu(hm).detach().cpu().requires_grad_(True)
+    olos.morphology_shape_loss(hr, tgt.cpu(), w.cpu(), 1.2, 0.5).backward()
+    hd = torch.relu(hm).detach().requires_grad_(True)
+    L.MorphologyShapeLoss(1.2, 0.5)(hd, tgt, w).backward()
+    assert rel_err(C(hd.grad), hr.grad.numpy()) < 2e-4
 
 
 # ------------------------------------------------------------------------------------------------ optimiser

@@ -72,6 +72,14 @@ int pk_affine_coords(const float* coords, const float* center, const float* scal
 int pk_flip_merge(const float* a, const float* b_flipped, const int32_t* partner, float* out,
                   int B, int K, int H, int W, void* stream);
 
+/* ---- video post-processing (utils/postprocess.py:187-267) -------------------------------------------------------
+ * pk_temporal_smooth: coords/out (T, C=2K) fp32, weights: `window` doubles as np.convolve receives them (the kernel is flipped
+ * like np.convolve does; edge padding window/2 on both sides; float64 accumulation, float32 result); window must be odd.
+ * pk_nms_pose: greedy in-sample suppression, preds (B,K,2), maxvals (B,K), out (B,K,2) = preds * keep, keep (B,K) uint8.     */
+int pk_temporal_smooth(const float* coords, float* out, const double* weights, int T, int C, int window, void* stream);
+int pk_nms_pose(const float* preds, const float* maxvals, float* out, uint8_t* keep, int B, int K, float distance_threshold,
+                void* stream);
+
 /* ---- L1/L2: FusionPoseLoss.forward (models/fusion_head.py:745-806 with :405-559, :637-743) ---------------
  * stats: workspace of B*K*PK_LOSS_STAT floats + B*16*4 floats + 16 floats (see PK_LOSS_WS_FLOATS);
  * losses: 7 floats (heatmap, offset, peak, variance, overlap, shape, total — already multiplied by lambdas). */

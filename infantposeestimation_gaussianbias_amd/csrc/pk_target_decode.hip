@@ -374,3 +374,69 @@ extern "C" int pk_flip_merge(const float* a, const float* b_flipped, const int32
     hipLaunchKernelGGL(k_flip_merge, dim3(B * K), dim3(256), 0, (hipStream_t)stream, a, b_flipped, partner, out, K, H, W);
     return pk_launch_status("pk_flip_merge");
 }
+
+// ================================================================================================ video post-processing
+// utils/postprocess.py::temporal_smoothing (:187-223): per joint coordinate, edge-padded trajectory convolved (np.convolve,
+// i.e. with the kernel FLIPPED) with `w` weights, evaluated in float64 and stored as float32 like the reference's
+// numpy-float64 -> float32 tensor assignment.  coords/out: (T, C) with C = 2K; weights: w doubles; w must be odd (the
+// reference's output has T+1 entries for even windows and its assignment fails).
+__global__ void __launch_bounds__(256) k_temporal_smooth(const float* __restrict__ coords, float* __restrict__ out,
+                                                         const double* __restrict__ weights, int T, int C, int w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * C) return;
+    const int t = i / C, c = i - t * C, half = w / 2;
+    double acc = 0.0;
+    for (int j = 0; j < w; ++j) {
+        int src = t + (w - 1 - j) - half;                 // padded index t + w-1-j, minus the left pad
+        src = src < 0 ? 0 : (src >= T ? T - 1 : src);     // mode='edge'
+        acc += (double)coords[(size_t)src * C + c] * weights[j];
+    }
+    out[i] = (float)acc;
+}
+extern "C" int pk_temporal_smooth(const float* coords, float* out, const double* weights, int T, int C, int window, void* stream) {
+    PK_REQUIRE(coords && out && weights && T > 0 && C > 0 && window > 0, "pk_temporal_smooth: bad argument");
+    PK_SUPPORTED((window & 1) == 1, "pk_temporal_smooth: window %d must be odd (the reference fails on even windows)", window);
+    hipLaunchKernelGGL(k_temporal_smooth, dim3((T * C + 255) / 256), dim3(256), 0, (hipStream_t)stream, coords, out, weights, T, C, window);
+    return pk_launch_status("pk_temporal_smooth");
+}
+
+// utils/postprocess.py::nms_pose (:241-267): greedy, order-dependent suppression inside one sample -> one thread per sample
+// walks the joints exactly like the reference's Python loop (distances on the ORIGINAL coordinates, `nearby` includes the
+// joint itself and already-suppressed joints, first maximum wins ties).
+__global__ void __launch_bounds__(64) k_nms_pose(const float* __restrict__ preds, const float* __restrict__ maxvals,
+                                                 float* __restrict__ out, uint8_t* __restrict__ keep, int B, int K, float thr) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const float* p = preds + (size_t)b * K * 2;
+    const float* v = maxvals + (size_t)b * K;
+    uint8_t* kp = keep + (size_t)b * K;
+    for (int k = 0; k < K; ++k) kp[k] = 1;
+    for (int k = 0; k < K; ++k) {
+        if (!kp[k]) continue;
+        int count = 0, best = -1;
+        float bv = -INFINITY;
+        for (int j = 0; j < K; ++j) {
+            const float dx = p[2 * j] - p[2 * k], dy = p[2 * j + 1] - p[2 * k + 1];
+            if (sqrtf(dx * dx + dy * dy) < thr) {
+                ++count;
+                if (v[j] > bv) { bv = v[j]; best = j; }
+            }
+        }
+        if (count > 1)
+            for (int j = 0; j < K; ++j) {
+                const float dx = p[2 * j] - p[2 * k], dy = p[2 * j + 1] - p[2 * k + 1];
+                if (sqrtf(dx * dx + dy * dy) < thr && j != best) kp[j] = 0;
+            }
+    }
+    for (int k = 0; k < K; ++k) {
+        const float m = kp[k] ? 1.f : 0.f;
+        out[((size_t)b * K + k) * 2] = p[2 * k] * m;
+        out[((size_t)b * K + k) * 2 + 1] = p[2 * k + 1] * m;
+    }
+}
+extern "C" int pk_nms_pose(const float* preds, const float* maxvals, float* out, uint8_t* keep, int B, int K, float distance_threshold,
+                           void* stream) {
+    PK_REQUIRE(preds && maxvals && out && keep && B > 0 && K > 0, "pk_nms_pose: bad argument");
+    hipLaunchKernelGGL(k_nms_pose, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, preds, maxvals, out, keep, B, K, distance_threshold);
+    return pk_launch_status("pk_nms_pose");
+}

@@ -218,6 +218,24 @@ def spatial_stats(hm):
     return _SpatialStats.apply(hm)
 
 
+def temporal_smooth(coords, kernel):
+    coords = _chk(coords)
+    T, K, _ = coords.shape
+    w = torch.as_tensor(kernel, dtype=torch.float64).to(coords.device)
+    out = torch.empty_like(coords)
+    call("pk_temporal_smooth", coords, out, w, T, K * 2, int(w.numel()), stream_ptr())
+    return out
+
+
+def nms_pose(preds, maxvals, distance_threshold=5.0):
+    preds, maxvals = _chk(preds), _chk(maxvals.reshape(preds.shape[0], preds.shape[1]))
+    B, K, _ = preds.shape
+    out = torch.empty_like(preds)
+    keep = torch.empty(B, K, dtype=torch.uint8, device=preds.device)
+    call("pk_nms_pose", preds, maxvals, out, keep, B, K, float(distance_threshold), stream_ptr())
+    return out, keep.bool().view(B, K, 1)
+
+
 # ------------------------------------------------------------------------------------------------ optimiser
 def adamw_step(param, grad, exp_avg, exp_avg_sq, flags, param_bf16, lr_dev, step_dev, beta1, beta2, eps, weight_decay, grad_scale=1.0):
     call("pk_adamw_step", param, grad, exp_avg, exp_avg_sq, flags, param_bf16, param.numel(), lr_dev, step_dev, float(beta1), float(beta2),

@@ -40,6 +40,25 @@ def filter_low_confidence(preds, maxvals, threshold=0.3):
     return preds * mask, mask
 
 
+def temporal_smoothing(coords_sequence, window_size=5, method="gaussian"):
+    """Reference signature (utils/postprocess.py:187-223): (T,K,2) trajectories smoothed along T on the device (one launch
+    instead of 2K numpy round trips).  The weights are built exactly as the reference builds them (float64, one-sided
+    'gaussian' or uniform); even windows raise like the reference's shape mismatch does."""
+    import numpy as np
+    if method == "gaussian":
+        sigma = window_size / 3.0
+        kernel = np.exp(-np.arange(window_size) ** 2 / (2 * sigma ** 2))
+        kernel = kernel / kernel.sum()
+    else:
+        kernel = np.ones(window_size) / window_size
+    return hipops.temporal_smooth(coords_sequence, kernel)
+
+
+def nms_pose(preds, maxvals, distance_threshold=5.0):
+    """Reference signature (utils/postprocess.py:241-267): -> (preds * keep, keep (B,K,1) bool)."""
+    return hipops.nms_pose(preds, maxvals, distance_threshold)
+
+
 def transform_preds(coords, center, scale, output_size, input_size=[256, 256]):
     return hipops.affine_coords(coords.float(), center.float().to(coords.device), scale.float().to(coords.device),
                                 1.0 / input_size[0], 1.0 / input_size[1])

@@ -194,3 +194,43 @@ def flip_merge(hm, hm_from_flipped, flip_pairs):
     for a, b in flip_pairs:
         sw[:, a], sw[:, b] = back[:, b], back[:, a]
     return ((hm + sw) / F32(2)).astype(F32)
+
+
+def temporal_smoothing(coords, window_size=5, method="gaussian"):
+    """utils/postprocess.py:187-223: per joint coordinate np.convolve(edge-padded trajectory, kernel, 'valid'); the 'gaussian'
+    kernel is the reference's one-sided exp(-n^2/(2 sigma^2)), n = 0..w-1, sigma = w/3, normalised.  coords (T,K,2) float32."""
+    coords = np.asarray(coords, np.float32)
+    T, K, _ = coords.shape
+    if method == "gaussian":
+        sigma = window_size / 3.0
+        kernel = np.exp(-np.arange(window_size) ** 2 / (2 * sigma ** 2))
+        kernel = kernel / kernel.sum()
+    else:
+        kernel = np.ones(window_size) / window_size
+    half = window_size // 2
+    out = coords.copy()
+    for k in range(K):
+        for d in range(2):
+            padded = np.pad(coords[:, k, d], (half, half), mode="edge")
+            out[:, k, d] = np.convolve(padded, kernel, mode="valid").astype(np.float32)
+    return out
+
+
+def nms_pose(preds, maxvals, distance_threshold=5.0):
+    """utils/postprocess.py:241-267 restated loop for loop.  preds (B,K,2), maxvals (B,K,1) -> (preds*keep, keep (B,K,1) bool)."""
+    preds, maxvals = np.asarray(preds, np.float32), np.asarray(maxvals, np.float32)
+    B, K, _ = preds.shape
+    keep = np.ones((B, K, 1), bool)
+    for b in range(B):
+        for k in range(K):
+            if not keep[b, k, 0]:
+                continue
+            dist = np.sqrt(((preds[b] - preds[b, k]) ** 2).sum(1, dtype=np.float32))
+            nearby = dist < np.float32(distance_threshold)
+            idx = np.where(nearby)[0]
+            if len(idx) > 1:
+                best = idx[int(np.argmax(maxvals[b, idx, 0]))]
+                for j in idx:
+                    if j != best:
+                        keep[b, j, 0] = False
+    return preds * keep.astype(np.float32), keep

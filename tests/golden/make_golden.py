@@ -525,6 +525,33 @@ def cap_models():
     return meta
 
 
+def cap_video():
+    """utils/postprocess.py::temporal_smoothing / nms_pose (video post-processing)."""
+    from utils import postprocess as pp
+    rng = np.random.default_rng(77)
+    out = {}
+    traj = (np.cumsum(rng.normal(0, 1.5, (23, 17, 2)), 0) + rng.uniform(0, 48, (1, 17, 2))).astype(np.float32)
+    out["ts_in"] = traj
+    for w in (3, 5, 7):
+        out[f"ts_gauss_w{w}"] = N(pp.temporal_smoothing(T(traj), w, "gaussian"))
+        out[f"ts_avg_w{w}"] = N(pp.temporal_smoothing(T(traj), w, "moving_average"))
+    short = traj[:2]
+    out["ts_short_in"], out["ts_short_w5"] = short, N(pp.temporal_smoothing(T(short), 5, "gaussian"))
+    # nms: clustered joints (several within 5 px of each other), ties in confidence, isolated joints
+    preds = rng.uniform(0, 40, (6, 17, 2)).astype(np.float32)
+    preds[:, 3] = preds[:, 2] + rng.uniform(-2, 2, (6, 2)).astype(np.float32)
+    preds[:, 9] = preds[:, 2] + rng.uniform(-3, 3, (6, 2)).astype(np.float32)
+    preds[:, 12] = preds[:, 11] + 1.0
+    preds[1, 5] = preds[1, 4]
+    conf = rng.uniform(0.1, 1.0, (6, 17, 1)).astype(np.float32)
+    conf[1, 5] = conf[1, 4]
+    out["nms_preds"], out["nms_conf"] = preds, conf
+    for thr in (5.0, 2.0, 12.0):
+        kept, mask = pp.nms_pose(T(preds), T(conf), thr)
+        out[f"nms_out_t{int(thr)}"], out[f"nms_keep_t{int(thr)}"] = N(kept), N(mask).astype(np.uint8)
+    save("video_post.npz", **out)
+
+
 def cap_base():
     """HRFormer-base + fusion head, K=13 (BASELINE cfg 5 at reduced resolution): C=(78,156,312,624), head_dim 39 -- the
     configuration whose channel counts are not multiples of 8 (exercises the padded-twin path of the build)."""
@@ -596,6 +623,10 @@ def cap_schedule():
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "video":      # add the video post-processing fixtures only
+        cap_video()
+        print("done (video)")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "base":       # add the HRFormer-base fixtures without touching the others
         with open(os.path.join(HERE, "meta.json")) as f:
             meta = json.load(f)
@@ -615,6 +646,7 @@ def main():
     meta["models"] = cap_models()
     meta["schedule"] = cap_schedule()
     meta["base"] = cap_base()
+    cap_video()
     meta["torch"] = torch.__version__
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, separators=(",", ":"))

@@ -225,6 +225,23 @@ def test_named_losses_vs_golden(golden, tag):
     assert rel_err(C(hd.grad), hr.grad.numpy()) < 2e-4
 
 
+def test_video_postprocess_kernels_vs_golden(golden):
+    """pk_temporal_smooth / pk_nms_pose against the reference's outputs (float64 convolution stored as float32: exact up to the
+    summation order of <= 7 doubles; suppression masks: identical)."""
+    from infantposeestimation_gaussianbias_amd.utils import postprocess as pp
+    z = golden("video_post.npz")
+    for w in (3, 5, 7):
+        assert np.abs(C(pp.temporal_smoothing(G(z["ts_in"]), w, "gaussian")) - z[f"ts_gauss_w{w}"]).max() < 2e-5
+        assert np.abs(C(pp.temporal_smoothing(G(z["ts_in"]), w, "moving_average")) - z[f"ts_avg_w{w}"]).max() < 2e-5
+    assert np.abs(C(pp.temporal_smoothing(G(z["ts_short_in"]), 5, "gaussian")) - z["ts_short_w5"]).max() < 2e-5
+    with pytest.raises(Exception):
+        pp.temporal_smoothing(G(z["ts_in"]), 4, "gaussian")                       # the reference fails on even windows too
+    for thr in (5, 2, 12):
+        kept, keep = pp.nms_pose(G(z["nms_preds"]), G(z["nms_conf"]), float(thr))
+        assert keep.shape == (6, 17, 1) and keep.dtype == torch.bool
+        assert np.array_equal(C(keep).astype(np.uint8), z[f"nms_keep_t{thr}"]) and np.array_equal(C(kept), z[f"nms_out_t{thr}"])
+
+
 # ------------------------------------------------------------------------------------------------ optimiser
 def test_fused_adamw_matches_oracle():
     from infantposeestimation_gaussianbias_amd import engine

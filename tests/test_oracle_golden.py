@@ -323,6 +323,19 @@ def test_hrformer_small_train_step(golden):
             assert rel_err(P[k[16:]].detach().numpy(), z[k]) < 1e-4, k
 
 
+def test_video_postprocess_vs_golden(golden):
+    """utils/postprocess.py::temporal_smoothing (:187-223) and nms_pose (:241-267) restated in oracle/decode.py."""
+    z = golden("video_post.npz")
+    for w in (3, 5, 7):
+        assert np.array_equal(odec.temporal_smoothing(z["ts_in"], w, "gaussian"), z[f"ts_gauss_w{w}"])
+        assert np.array_equal(odec.temporal_smoothing(z["ts_in"], w, "moving_average"), z[f"ts_avg_w{w}"])
+    assert np.array_equal(odec.temporal_smoothing(z["ts_short_in"], 5, "gaussian"), z["ts_short_w5"])
+    for thr in (5, 2, 12):
+        kept, keep = odec.nms_pose(z["nms_preds"], z["nms_conf"], float(thr))
+        assert np.array_equal(keep.astype(np.uint8), z[f"nms_keep_t{thr}"]) and np.array_equal(kept, z[f"nms_out_t{thr}"])
+    assert not z["nms_keep_t5"].all() and z["nms_keep_t5"].any()      # the fixture really suppresses something
+
+
 def test_hrformer_base_eval_and_train_step(golden):
     """HRFormer-base + fusion head, K=13 (BASELINE cfg 5 at 128x96): the oracle against the reference's fp32 outputs for the
     configuration whose channels are not multiples of 8 (C = 78, head_dim 39) -- the fixtures the padded-twin GPU tests use."""

@@ -176,6 +176,7 @@ def main():
                        "launch": ("hipGraph replay" if trainer._graph is not None else "eager launches") +
                        (", branches on concurrent HIP streams" if dispatch.streams_enabled() else ", single stream")},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
+            "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
             "impl": dict(impl_table, loss="hip", target="hip", decode="hip", adamw="hip"),
             "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP ({dispatch.backend_name(model)}); no PyTorch/CPU fallback exists",
         }

@@ -346,8 +346,17 @@ class Trainer:
         self._static = {k: batch[k].clone() for k in keys}
         self._graph_has_opt = self.comm.world == 1
         torch.cuda.synchronize()
+        mode = "global"
+        if self.comm.world > 1:
+            # The process group's watchdog thread polls the events of outstanding collectives (cudaEventQuery); under the
+            # default global capture mode such a call from another thread invalidates the capture.  All collectives have
+            # completed (synchronize above); give the watchdog one polling period to retire them, and only police the
+            # capturing threads' own calls.
+            import time
+            time.sleep(0.5)
+            mode = "thread_local"
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self._stream):
+        with torch.cuda.graph(g, stream=self._stream, capture_error_mode=mode):
             out = self._fwd_bwd(self._static)
             if self._graph_has_opt:
                 self.opt.step(1.0)

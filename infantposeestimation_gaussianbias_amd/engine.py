@@ -360,6 +360,8 @@ class Trainer:
             out = self._fwd_bwd(self._static)
             if self._graph_has_opt:
                 self.opt.step(1.0)
+        if self._graph_has_opt:
+            self.opt.step_count -= 1          # the captured optimiser launch did not execute; _graph_step counts the replays
         self._graph, self._static_out = g, out
 
     def _graph_step(self, batch):
@@ -397,4 +399,12 @@ class Trainer:
                     bk["need"] = -2               # never "complete" by counting; finish() flushes every bucket
             self._capture(batch)
             # the capture itself does not execute: run this step through the graph
+        if any(k not in batch or batch[k] is None or batch[k].shape != v.shape for k, v in self._static.items()):
+            # a batch the captured graph was not recorded for (e.g. the short last batch of an epoch): launch it eagerly on the
+            # capture stream, with the same autograd structure and the same optimiser path as the replayed steps
+            self._stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self._stream):
+                out = self._eager_step(batch)
+            torch.cuda.current_stream().wait_stream(self._stream)
+            return out
         return self._graph_step(batch)

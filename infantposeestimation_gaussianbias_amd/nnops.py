@@ -63,7 +63,7 @@ _REDUCE_DTYPE = np.dtype([("part", "<i8"), ("out", "<i8"), ("stride", "<i8"), ("
                           ("N", "<i4"), ("T", "<i4"), ("Cin", "<i4"), ("ostride", "<i4"), ("pad", "<i4")])
 _WS = {}                # (sink data_ptr, tag) -> persistent fp32 workspace
 _PENDING = []           # rows registered since the last finalize
-_TABLE = {"key": None}
+_TABLES = {}            # key (tuple of rows) -> device table; never evicted: a captured hipGraph may hold its pointers
 
 
 def deferral_enabled():
@@ -89,7 +89,8 @@ def finalize_deferred():
         return
     key = tuple(_PENDING)
     _PENDING.clear()
-    if _TABLE["key"] != key:
+    tab = _TABLES.get(key)
+    if tab is None:
         if torch.cuda.is_current_stream_capturing():
             raise _lib.PoseKernelError("deferred-reduction table changed during hipGraph capture (host->device table upload is not "
                                        "capturable): run at least two eager warm-up steps before capturing")
@@ -101,9 +102,10 @@ def finalize_deferred():
             blk_desc += [i] * k
             blk_first += [nb] * k
             nb += k
-        _TABLE.update(key=key, desc=torch.from_numpy(desc.view(np.uint8)).to(dev), nb=nb,
-                      blk_desc=torch.tensor(blk_desc, dtype=I32, device=dev), blk_first=torch.tensor(blk_first, dtype=I32, device=dev))
-    call("pk_reduce_many", _TABLE["desc"], _TABLE["blk_desc"], _TABLE["blk_first"], _TABLE["nb"], stream_ptr())
+        tab = _TABLES[key] = dict(desc=torch.from_numpy(desc.view(np.uint8)).to(dev), nb=nb,
+                                  blk_desc=torch.tensor(blk_desc, dtype=I32, device=dev),
+                                  blk_first=torch.tensor(blk_first, dtype=I32, device=dev))
+    call("pk_reduce_many", tab["desc"], tab["blk_desc"], tab["blk_first"], tab["nb"], stream_ptr())
 
 
 # ================================================================================================ weight cache

@@ -560,6 +560,30 @@ def test_region_mode_gradients_match_stream_mode():
     assert float((a - b).norm() / a.norm()) < 2e-2           # bf16 re-association of fan-out gradient sums only
 
 
+def test_graph_trainer_takes_an_odd_sized_batch_eagerly():
+    """A batch whose shape differs from the captured one (short last batch of an epoch) is launched eagerly, then replays resume."""
+    from infantposeestimation_gaussianbias_amd import dispatch, engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    full = synthetic_batch(4, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=1)
+    short = synthetic_batch(3, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=2)
+    try:
+        torch.manual_seed(0)
+        model = build_model(cfg).to(DEV)
+        model.backbone.drop_path_rate = 0.0
+        tr = engine.Trainer(model, cfg, iters_per_epoch=2, use_graph=True, graph_warmup=2, graph_streams=True)
+        losses = [float(tr.step(full)["loss"].detach()) for _ in range(4)]
+        assert tr._graph is not None
+        losses.append(float(tr.step(short)["loss"].detach()))          # eager
+        losses.append(float(tr.step(full)["loss"].detach()))           # replay again
+        assert np.all(np.isfinite(losses)) and tr.opt.step_count == 6
+    finally:
+        dispatch.set_region_mode(False)
+
+
 def test_deferred_reductions_match_inline_reductions(monkeypatch):
     """Parameter gradients with the slab reductions postponed to ONE pk_reduce_many launch equal the ones produced by the
     per-layer reduce kernels (same slabs; only LayerNorm / rel-pos-bias sums use a different fixed summation tree)."""

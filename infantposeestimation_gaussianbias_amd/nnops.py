@@ -71,10 +71,16 @@ def deferral_enabled():
     return os.environ.get("POSE_DEFER_REDUCE", "1") != "0"
 
 
+_WS_FROZEN = [False]    # set once a hipGraph that uses the workspaces has been captured (engine.Trainer)
+
+
 def _workspace(sink, tag, numel):
     key = (sink.data_ptr(), tag)
     ws = _WS.get(key)
     if ws is None or ws.numel() < numel or ws.device != sink.device:
+        if ws is not None and _WS_FROZEN[0]:
+            raise _lib.PoseKernelError("a slab workspace would have to grow after a hipGraph was captured with it (a batch larger "
+                                       "than the captured one?): capture with the largest batch or use eager mode")
         ws = _WS[key] = torch.empty(numel, dtype=F32, device=sink.device)
     return ws
 

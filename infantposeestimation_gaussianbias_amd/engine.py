@@ -363,7 +363,7 @@ class Trainer:
         if self._graph_has_opt:
             self.opt.step_count -= 1          # the captured optimiser launch did not execute; _graph_step counts the replays
         self._graph, self._static_out = g, out
-        nnops._WS_FROZEN[0] = True            # the graph holds the slab-workspace pointers: they must not be reallocated
+        nnops.freeze_workspaces(self.model)   # the graph holds the slab-workspace pointers: they must not be reallocated
 
     def _graph_step(self, batch):
         for k, v in self._static.items():

@@ -61,7 +61,6 @@ def _up8(n):
 # of them with ONE pk_reduce_many launch.  ~360 launches per step leave the data-gradient chain.
 _REDUCE_DTYPE = np.dtype([("part", "<i8"), ("out", "<i8"), ("stride", "<i8"), ("S", "<i4"), ("K", "<i4"), ("layout", "<i4"),
                           ("N", "<i4"), ("T", "<i4"), ("Cin", "<i4"), ("ostride", "<i4"), ("pad", "<i4")])
-_WS = {}                # (sink data_ptr, tag) -> persistent fp32 workspace
 _PENDING = []           # rows registered since the last finalize
 _TABLES = {}            # key (tuple of rows) -> device table; never evicted: a captured hipGraph may hold its pointers
 
@@ -71,18 +70,32 @@ def deferral_enabled():
     return os.environ.get("POSE_DEFER_REDUCE", "1") != "0"
 
 
-_WS_FROZEN = [False]    # set once a hipGraph that uses the workspaces has been captured (engine.Trainer)
-
-
 def _workspace(sink, tag, numel):
-    key = (sink.data_ptr(), tag)
-    ws = _WS.get(key)
-    if ws is None or ws.numel() < numel or ws.device != sink.device:
-        if ws is not None and _WS_FROZEN[0]:
+    """Persistent fp32 workspace attached to the gradient-sink tensor it serves (lives and dies with the model's gradient
+    buffer, so a captured hipGraph can keep its pointer).  `freeze_workspaces` marks them after a capture."""
+    d = getattr(sink, "_pk_ws", None)
+    if d is None:
+        d = sink._pk_ws = {}
+    ws = d.get(tag)
+    if ws is None or ws.numel() < numel:
+        if ws is not None and getattr(sink, "_pk_ws_frozen", False):
             raise _lib.PoseKernelError("a slab workspace would have to grow after a hipGraph was captured with it (a batch larger "
                                        "than the captured one?): capture with the largest batch or use eager mode")
-        ws = _WS[key] = torch.empty(numel, dtype=F32, device=sink.device)
+        ws = d[tag] = torch.empty(numel, dtype=F32, device=sink.device)
     return ws
+
+
+def freeze_workspaces(model):
+    """Called after a hipGraph capture: the graph holds the workspace pointers of every gradient sink of `model`."""
+    mods = [model]
+    tw = getattr(model, "_pk_twin", None)
+    if tw:
+        mods.append(tw.twin)
+    for m in mods:
+        for p in m.parameters():
+            sk = getattr(p, "_pk_grad_sink", None)
+            if sk is not None:
+                sk._pk_ws_frozen = True
 
 
 def _defer(part_ptr, out, slab_stride, S, K, layout=0, N=0, T=1, Cin=1, out_stride=1, out_offset=0):

@@ -319,6 +319,7 @@ class Trainer:
 
     # -- eager path --------------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch):
+        nnops._PENDING.clear()         # reductions registered by a step that did not finish (exception) must not leak into this one
         self.opt.zero_grad()
         out = self.model(batch["img"], batch["target"], batch["target_weight"], gt_keypoints=batch.get("keypoints"),
                          input_size=self.cfg.data.input_size)

@@ -219,6 +219,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     const int kc = tid % CH;                         // this thread's chunk column (same for all its rows: 256 % CH == 0)
     const int row0 = tid / CH;                       // first staged row; further rows are +256/CH apart
     constexpr int RSTEP = 256 / CH;
+    // LDS-DMA staging (256-row tile): `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 bytes to LDS at a wave-uniform base +
+    // lane * 16, with no VGPR destination and no ds_write.  The lanes of a wave stage 16 consecutive rows x 4 chunks, which is
+    // exactly lane-linear in the unpadded [row][BK = 32] tile; the XOR swizzle therefore moves to the SOURCE side: the lane
+    // at physical chunk position kc fetches logical chunk kc ^ swz(row) (the fragment reads are unchanged).
+    constexpr bool DMA = (BM == 256 && BK == 32);
+    const int kcg = DMA ? (kc ^ swz<BK>(row0)) : kc;   // chunk index on the global side (swz depends on row bit 3 only: same for row0 + 64 i)
 
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, 0x7ffffff0, 0x00020000);
@@ -248,7 +254,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
         const int q = tid + 256 * i, n = n0 + q / CH;
-        b_off[i] = (q < BN * CH && n < p.N) ? (unsigned)((n * p.T * p.Cin + kc * 8) * 2) : OOB_OFF;
+        b_off[i] = (q < BN * CH && n < p.N) ? (unsigned)((n * p.T * p.Cin + kcg * 8) * 2) : OOB_OFF;
     }
     const int kchunks = (p.Cin + BK - 1) / BK;
     const int nk = p.T * kchunks;
@@ -261,7 +267,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             unsigned off = OOB_OFF;
             if (a_ok[i]) {
                 if (linear) {
-                    off = (unsigned)((a_base[i] + kc * 8) * 2);
+                    off = (unsigned)((a_base[i] + kcg * 8) * 2);
                 } else {
                     int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
                     bool ok = true;
@@ -271,7 +277,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
                         ix >>= 1;
                     }
                     if (ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
-                        off = (unsigned)((a_base[i] + (iy * p.Ws + ix) * p.Cin + kc * 8) * 2);
+                        off = (unsigned)((a_base[i] + (iy * p.Ws + ix) * p.Cin + kcg * 8) * 2);
                 }
             }
             a_voff[i] = off;
@@ -284,8 +290,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     // tiling (64x64 wave tiles: 768 LDS cycles per 512 MFMA cycles and K-step).  The deep variant is kept for BK = 64.
     constexpr bool FRAG_PREFETCH = !DEEP;
     u32x4 ra[A_PT], rb[B_PT], ra2[DEEP ? A_PT : 1], rb2[DEEP ? B_PT : 1];
+    auto dma_tiles = [&](int buf, int t, int c0) {       // global -> LDS without registers (DMA variant only)
+#if defined(__HIP_DEVICE_COMPILE__)    // the builtin needs a gfx950 target feature: the host pass of hipcc must not see it
+        const bool c_ok = (c0 + kcg * 8) < p.Cin;
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(&sA[buf * BM * BK + (wave * 16 + RSTEP * i) * BK]),
+                                                     16, c_ok ? a_voff[i] : OOB_OFF, c0 * 2, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(&sB[buf * BN * BK + (wave * 16 + RSTEP * i) * BK]),
+                                                     16, c_ok ? b_off[i] : OOB_OFF, (t * p.Cin + c0) * 2, 0, 0);
+#endif
+    };
     auto load_tiles = [&](u32x4* ra, u32x4* rb, int t, int c0) {       // c0: first channel of this K-chunk (wave-uniform)
-        const bool c_ok = (c0 + kc * 8) < p.Cin;
+        const bool c_ok = (c0 + kcg * 8) < p.Cin;
 #pragma unroll
         for (int i = 0; i < A_PT; ++i)
             ra[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, c_ok ? a_voff[i] : OOB_OFF, c0 * 2, 0);
@@ -378,6 +397,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         }
     };
     set_tap(0);
+    if constexpr (DMA) {
+        static_assert(CH == 4 && BM % 64 == 0 && BN % 64 == 0, "lane-linear LDS-DMA layout needs 64-byte tile rows");
+        dma_tiles(0, 0, 0);
+        __syncthreads();                              // drains vmcnt(0): tile 0 is in LDS
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) {
+                advance();
+                dma_tiles(buf ^ 1, t_next, c_next);   // the other buffer was last read before the barrier that ended step kt-1
+            }
+            compute(buf);
+            __syncthreads();
+        }
+    } else {
     load_tiles(ra, rb, 0, 0);
     store_tiles(ra, rb, 0);
     if constexpr (!DEEP) {
@@ -421,6 +454,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             __syncthreads();
         }
     }
+
+    }   // !DMA
 
     // ---- BatchNorm statistics of the raw fp32 accumulators (rows >= M contribute exact zeros)
     if (p.stats) {

@@ -399,6 +399,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     set_tap(0);
     if constexpr (DMA) {
         static_assert(CH == 4 && BM % 64 == 0 && BN % 64 == 0, "lane-linear LDS-DMA layout needs 64-byte tile rows");
+        // (Tried on top: three LDS stages, loads two tiles ahead, one raw s_barrier per K-step with a counted `s_waitcnt vmcnt(6)`
+        // so the DMA stays in flight across the barrier -- correct, but 313 / 270 us instead of 304 / 264 us: at two workgroups
+        // per CU the other workgroup already covers the load latency; the remaining bound is LDS bandwidth.)
         dma_tiles(0, 0, 0);
         __syncthreads();                              // drains vmcnt(0): tile 0 is in LDS
         for (int kt = 0; kt < nk; ++kt) {

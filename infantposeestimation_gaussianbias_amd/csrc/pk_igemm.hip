@@ -219,11 +219,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     const int kc = tid % CH;                         // this thread's chunk column (same for all its rows: 256 % CH == 0)
     const int row0 = tid / CH;                       // first staged row; further rows are +256/CH apart
     constexpr int RSTEP = 256 / CH;
-    // LDS-DMA staging (256-row tile): `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 bytes to LDS at a wave-uniform base +
-    // lane * 16, with no VGPR destination and no ds_write.  The lanes of a wave stage 16 consecutive rows x 4 chunks, which is
-    // exactly lane-linear in the unpadded [row][BK = 32] tile; the XOR swizzle therefore moves to the SOURCE side: the lane
-    // at physical chunk position kc fetches logical chunk kc ^ swz(row) (the fragment reads are unchanged).
-    constexpr bool DMA = (BM == 256 && BK == 32);
+    // LDS-DMA staging (tiles with BN >= 128: the MFMA-bound layers): `buffer_load_dwordx4 ... lds` writes 64 lanes x 16 bytes
+    // to LDS at a wave-uniform base + lane * 16, with no VGPR destination and no ds_write.  The lanes of a wave stage 64/CH
+    // consecutive rows x CH chunks, which is exactly lane-linear in the unpadded [row][BK] tile; the XOR swizzle therefore moves
+    // to the SOURCE side: the lane at physical chunk position kc fetches logical chunk kc ^ swz(row) (the fragment reads are
+    // unchanged; swz depends on row bits below the row step, so one value per thread).  Frees 24-44 VGPRs per tile variant.
+    constexpr bool DMA = (BN >= 128);
     const int kcg = DMA ? (kc ^ swz<BK>(row0)) : kc;   // chunk index on the global side (swz depends on row bit 3 only: same for row0 + 64 i)
 
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
@@ -283,7 +284,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             a_voff[i] = off;
         }
     };
-    constexpr bool DEEP = (BN >= 128 && BK == 64);    // global loads issued TWO tiles ahead (second register set), see the main loop
+    constexpr bool DEEP = (BN >= 128 && BK == 64 && !DMA);    // global loads issued TWO tiles ahead (second register set), see the main loop
     // Fragment double-buffering (below) and the second global-load register set together need > 256 registers (occupancy 1:
     // head conv 526 us).  Measured one at a time on the 3x3 256->256 head conv (fwd / dgrad): neither 370 / 308 us, fragment
     // prefetch 352 / 302 us, deep global prefetch 359 / 302 us -- both hide latency, neither removes the ceiling of this
@@ -295,11 +296,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         const bool c_ok = (c0 + kcg * 8) < p.Cin;
 #pragma unroll
         for (int i = 0; i < A_PT; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(&sA[buf * BM * BK + (wave * 16 + RSTEP * i) * BK]),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(&sA[buf * BM * BK + (wave * (64 / CH) + RSTEP * i) * BK]),
                                                      16, c_ok ? a_voff[i] : OOB_OFF, c0 * 2, 0, 0);
 #pragma unroll
         for (int i = 0; i < B_PT; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(&sB[buf * BN * BK + (wave * 16 + RSTEP * i) * BK]),
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(&sB[buf * BN * BK + (wave * (64 / CH) + RSTEP * i) * BK]),
                                                      16, c_ok ? b_off[i] : OOB_OFF, (t * p.Cin + c0) * 2, 0, 0);
 #endif
     };
@@ -398,7 +399,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     };
     set_tap(0);
     if constexpr (DMA) {
-        static_assert(CH == 4 && BM % 64 == 0 && BN % 64 == 0, "lane-linear LDS-DMA layout needs 64-byte tile rows");
+        static_assert(BM % RSTEP == 0 && BN % RSTEP == 0 && (RSTEP % 16) == 0, "lane-linear LDS-DMA layout: whole 1-KiB pieces per wave instruction");
         // (Tried on top: three LDS stages, loads two tiles ahead, one raw s_barrier per K-step with a counted `s_waitcnt vmcnt(6)`
         // so the DMA stays in flight across the barrier -- correct, but 313 / 270 us instead of 304 / 264 us: at two workgroups
         // per CU the other workgroup already covers the load latency; the remaining bound is LDS bandwidth.)

@@ -402,7 +402,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         static_assert(BM % RSTEP == 0 && BN % RSTEP == 0 && (RSTEP % 16) == 0, "lane-linear LDS-DMA layout: whole 1-KiB pieces per wave instruction");
         // (Tried on top: three LDS stages, loads two tiles ahead, one raw s_barrier per K-step with a counted `s_waitcnt vmcnt(6)`
         // so the DMA stays in flight across the barrier -- correct, but 313 / 270 us instead of 304 / 264 us: at two workgroups
-        // per CU the other workgroup already covers the load latency; the remaining bound is LDS bandwidth.)
+        // per CU the other workgroup already covers the load latency; the remaining bound is LDS bandwidth.  The same pipeline on
+        // a 256 x 256 tile with 128 x 128 per wave (a third less LDS traffic again, one wave per SIMD): correct, but 256 + 256
+        // registers are not enough -- 796 bytes of scratch per lane, 417 / 316 us.)
         dma_tiles(0, 0, 0);
         __syncthreads();                              // drains vmcnt(0): tile 0 is in LDS
         for (int kt = 0; kt < nk; ++kt) {
@@ -489,8 +491,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         __syncthreads();
         constexpr int GROUPS = BM / STAT_ROWS, WPG = WM / GROUPS;        // statistics tiles per workgroup, wave rows per tile
         static_assert(BM % STAT_ROWS == 0 && WM % GROUPS == 0, "statistics tiles must be whole wave rows");
-        if (tid < BN * GROUPS && n0 + tid % BN < p.N) {
-            const int g = tid / BN, nl = tid % BN;
+        for (int e = tid; e < BN * GROUPS; e += 256) {       // (BN * GROUPS may exceed the 256 threads of the workgroup)
+            const int g = e / BN, nl = e % BN;
+            if (n0 + nl >= p.N) continue;
             float s = 0.f, q = 0.f;
 #pragma unroll
             for (int w = 0; w < WPG; ++w) {

@@ -148,49 +148,10 @@ def join_side_streams(cur=None):
         cur.wait_stream(s)
 
 
-# ---- weight-gradient side streams
-# Nothing in backward depends on a weight gradient until the optimiser, but on the branch's stream every wgrad + slab
-# reduce pair sits in the dependency chain of the data-gradient path (~500 of the ~2 000 launches per step, each with a few
-# microseconds of launch/drain latency).  When the gradient goes straight into the flat gradient buffer (gradient sink), the
-# weight-gradient kernels are issued on an auxiliary stream per branch stream (fork: aux waits on the branch stream's
-# current position) and are joined once, after backward (`join_aux`, called by the Trainer; under capture this is what
-# joins them into the graph).  MEASURED: slower (25.4 -> 31.0 ms/step in the captured graph at B=64): the wgrad grids
-# (>= 2 048 workgroups each) take CUs from the critical data-gradient chain instead of filling its bubbles, so this is OFF
-# unless POSE_AUX_WGRAD=1.
-_AUX = {}
-_AUX_DIRTY = {}
-
-
-def aux_wgrad_mode() -> int:
-    """0 = off (default), 1 = every sink-bound weight gradient, 2 = only the large 3x3 convs (the head)."""
-    return int(os.environ.get("POSE_AUX_WGRAD", "0")) if streams_enabled() else 0
-
-
-def aux_wgrad_enabled() -> bool:
-    return aux_wgrad_mode() > 0
-
-
-def aux_stream_for(cur, inputs):
-    """Auxiliary stream of `cur`, ordered after everything enqueued on `cur` so far; `inputs` are the tensors the aux work reads."""
-    aux = _AUX.get(cur.cuda_stream)
-    if aux is None:
-        aux = _AUX[cur.cuda_stream] = torch.cuda.Stream(device=cur.device)
-    _order(cur, aux)
-    for t in inputs:
-        if t is not None:
-            t.record_stream(aux)
-    _AUX_DIRTY[aux.cuda_stream] = aux
-    return aux
-
-
-def join_aux(cur=None):
-    """`cur` waits for all weight-gradient work issued on auxiliary streams since the last join."""
-    if not _AUX_DIRTY:
-        return
-    cur = cur or torch.cuda.current_stream()
-    for aux in _AUX_DIRTY.values():
-        _order(aux, cur)
-    _AUX_DIRTY.clear()
+# (Measured and removed: issuing the weight-gradient kernels on auxiliary streams -- they are off the data-gradient dependency
+# chain -- made the captured step SLOWER, 25.4 -> 31.0 ms for all of them and -1 % at best for the head's five large ones: their
+# >= 2 048-workgroup grids take CUs from the critical chain instead of filling its bubbles, and hipGraph maps parallel branches
+# onto 4 hardware queues (DEBUG_HIP_FORCE_GRAPH_QUEUES; more queues do not help).)
 
 
 def _tensors(obj):

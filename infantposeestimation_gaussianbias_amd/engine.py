@@ -324,8 +324,6 @@ class Trainer:
         out = self.model(batch["img"], batch["target"], batch["target_weight"], gt_keypoints=batch.get("keypoints"),
                          input_size=self.cfg.data.input_size)
         out["loss"].backward()
-        from . import dispatch
-        dispatch.join_aux()            # weight-gradient kernels issued on auxiliary streams (dispatch.aux_stream_for)
         nnops.finalize_deferred()      # ONE launch: all postponed slab reductions of parameter gradients
         tw = getattr(self.model, "_pk_twin", None)
         if tw:

@@ -272,18 +272,11 @@ def _conv_dgrad(g, wd, Cin, ksize, stride, in_hw):
 
 
 def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=None, g_rps=0, M=None, oihw=True, out=None,
-           dbias=None, deferred=False, _on_aux=False):
+           dbias=None, deferred=False):
     """-> fp32 gradient (N, Cin, k, k) for conv (geom=(B,Hs,Ws,Ho,Wo)) or (N, Cin) for linear (geom=None); `out` = destination.
     `dbias` (fp32, <= N entries) additionally receives the bias gradient (column sums of the same scaled/gathered rows).
-    `deferred=True` (only when every output is a gradient sink, i.e. nothing downstream in backward reads the result): the
-    kernels go to the auxiliary weight-gradient stream of the current stream (dispatch.aux_stream_for / join_aux)."""
-    if deferred and out is not None and not _on_aux:
-        from . import dispatch
-        mode = dispatch.aux_wgrad_mode()
-        if mode == 1 or (mode == 2 and ksize == 3 and N * Cin >= 128 * 256):
-            aux = dispatch.aux_stream_for(torch.cuda.current_stream(), (x, g, a_map, g_map, g_scale))
-            with torch.cuda.stream(aux):
-                return _wgrad(x, g, N, Cin, ksize, stride, geom, a_map, g_map, g_scale, g_rps, M, oihw, out, dbias, True, True)
+    `deferred=True` (only when every output is a gradient sink, i.e. nothing downstream in backward reads the result): only the
+    split-M slabs are written here, their reduction is postponed to finalize_deferred()."""
     T = ksize * ksize
     if geom is None:
         B = Hs = Ws = Ho = Wo = 0

@@ -139,6 +139,9 @@ extern "C" int pk_bn_act(const void* x, const float* scale, const float* shift, 
 }
 
 // Backward, pass 1: per-block partial sums over rows of g and g*xhat, g = dy * (y > 0 if relu).
+// (Measured and dropped: recomputing the ReLU mask from `raw` (scale/shift of the forward) to skip the read of `y` in both passes
+// made the step SLOWER, 21.97 -> 25.4 ms even with the path disabled at run time: the extra per-channel state costs these
+// bandwidth-bound kernels more than the saved 2 bytes per element.)
 // Block = 256 threads = (256/cchunks) row lanes x cchunks channel chunks; partial[block][2][C].
 #define BNR_MAXC 1024
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const uint4* __restrict__ dy, const uint4* __restrict__ yact,

@@ -132,10 +132,14 @@ def main():
     batch = synthetic_batch(PER_GPU_BATCH, INPUT_SIZE, HEATMAP_SIZE, K, 2.0, dev, seed=1234 + rank)
     args.warmup = max(args.warmup, 4) if use_graph else args.warmup      # 2 eager steps + capture + 1 replay before timing
 
-    out = None
+    from infantposeestimation_gaussianbias_amd import _lib
+    out, calls_per_step = None, None
     for i in range(args.warmup):
         t_w = time.perf_counter()
+        c0 = _lib.CALLS[0]
         out = trainer.step(batch)
+        if i == 1:
+            calls_per_step = _lib.CALLS[0] - c0      # second eager warm-up step: every kernel sequence issued from the host
         if rank == 0 and i < 3:
             torch.cuda.synchronize()
             log(f"warm-up step {i}: {time.perf_counter() - t_w:.3f} s")
@@ -177,6 +181,7 @@ def main():
                        (", branches on concurrent HIP streams" if dispatch.streams_enabled() else ", single stream")},
             "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
             "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
+            "c_abi_calls_per_step": calls_per_step,
             "impl": dict(impl_table, loss="hip", target="hip", decode="hip", adamw="hip"),
             "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP ({dispatch.backend_name(model)}); no PyTorch/CPU fallback exists",
         }

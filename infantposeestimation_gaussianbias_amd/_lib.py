@@ -58,8 +58,12 @@ def _load():
 lib = _load()
 
 
+CALLS = [0]      # number of C-ABI calls made so far (bench.py reports the per-step count; one call = one to three kernel launches)
+
+
 def call(name, *args):
     """Invoke a pk_* entry; tensors are passed as data_ptr(), None as NULL. Raises on any non-zero status."""
+    CALLS[0] += 1
     conv = []
     for a in args:
         if a is None:

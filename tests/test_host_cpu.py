@@ -149,7 +149,8 @@ def _dp_worker(rank, world, port, q, overlap):
         (y ** 2).sum().backward()
         comm.finish()
         grads.append(opt.grad.clone())
-    q.put((rank, opt.flat.clone(), grads, len(comm.buckets), list(opt.active)))
+    # numpy arrays are pickled by value (tensors travel as file descriptors that die with the exiting worker: flaky)
+    q.put((rank, opt.flat.detach().numpy().copy(), [g.numpy().copy() for g in grads], len(comm.buckets), list(opt.active)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -166,6 +167,7 @@ def test_gradient_exchange_world2_matches_single_process(overlap):
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
+    res = [(r, torch.from_numpy(f), [torch.from_numpy(g) for g in gs], nb_, act) for r, f, gs, nb_, act in res]
     (_, flat0, g0, nb, active), (_, flat1, g1, _, _) = res
     assert nb >= 3 and active[-2:] == [False, False]
     assert torch.equal(flat0, flat1)                                 # broadcast made ranks identical

@@ -7,7 +7,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement).  Synthetic devi
 seed 1234+rank), B=64 per GPU (weak scaling), DropPath on, BN in train mode, every parameter updated.
 Extra objects: `roofline` (dominant hand-written HIP kernel, timed live with HIP events on its launch stream),
 `cpu_baseline` (the CPU oracle = parity-pinned port of the reference, timed on this host's cores, rank 0 / N=1 only),
-`impl` (which network ops run as HIP kernels vs ATen stop-gaps — see nnops.IMPL).
+`--gpus N` without a torchrun environment starts N fresh ranks itself (one child process per GPU).
 """
 import argparse
 import json
@@ -21,7 +21,6 @@ import torch.distributed as dist
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-os.environ.setdefault("MIOPEN_FIND_MODE", "2")   # only matters while conv is still an ATen/MIOpen stop-gap (nnops.IMPL)
 
 
 def log(msg):
@@ -100,9 +99,25 @@ def main():
     ap.add_argument("--single-stream", action="store_true", help="do not run the resolution branches on concurrent HIP streams")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Plain `python bench.py --gpus N`: start N ranks ourselves, one fresh child process per GPU, BEFORE anything in this
+        # process touches the GPU (device_count() does not initialise it).  The children print the one JSON line (rank 0).
+        import socket
+        import subprocess
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_dev} GPU(s) visible")
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.run(cmd).returncode)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with --nproc-per-node {args.gpus} (or without torchrun)")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU implementation")
     torch.cuda.set_device(local)
@@ -110,8 +125,6 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
-    if args.gpus != world and rank == 0:
-        print(f"# note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
 
     from infantposeestimation_gaussianbias_amd import dispatch, engine, nnops
     from infantposeestimation_gaussianbias_amd.configs import get_config
@@ -168,8 +181,6 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline()
             log(f"cpu baseline: {cpu}")
-        impl_table = nnops.IMPL
-        n_hip = sum(v == "hip" for v in impl_table.values())
         line = {
             "metric": "images/sec (train fwd+bwd) HRFormer-S 256x192", "value": round(PER_GPU_BATCH * world * args.steps / dt, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -182,8 +193,7 @@ def main():
             "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
             "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
             "c_abi_calls_per_step": calls_per_step,
-            "impl": dict(impl_table, loss="hip", target="hip", decode="hip", adamw="hip"),
-            "impl_note": f"{n_hip}/{len(impl_table)} network op groups are hand-written HIP ({dispatch.backend_name(model)}); no PyTorch/CPU fallback exists",
+            "backend": dispatch.backend_name(model),
         }
         print(json.dumps(line))
     if world > 1:

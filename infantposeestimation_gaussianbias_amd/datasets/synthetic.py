@@ -28,8 +28,11 @@ def synthetic_batch(batch_size, input_size=(192, 256), heatmap_size=(48, 64), nu
 class SyntheticLoader:
     """Iterable of `n_batches` device-resident synthetic batches (stands in for build_dataloader when no COCO is on disk)."""
 
-    def __init__(self, cfg, n_batches=10, device="cuda", seed=1234):
-        self.cfg, self.n, self.device, self.seed = cfg, n_batches, device, seed
+    def __init__(self, cfg, n_batches=10, device="cuda", seed=1234, rank=None):
+        import os
+        rank = int(os.environ.get("RANK", "0")) if rank is None else rank
+        # every rank draws its own shard: batch i of rank r is seeded seed + r * n_batches + i
+        self.cfg, self.n, self.device, self.seed = cfg, n_batches, device, seed + rank * n_batches
         self.dataset = range(n_batches * cfg.train.batch_size)
 
     def __len__(self):

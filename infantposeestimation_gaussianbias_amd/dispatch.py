@@ -63,28 +63,8 @@ def ops():
     return _ACTIVE[-1]
 
 
-def to_features(x):
-    return ops().to_features(x)
-
-
-def conv_bn_act(x, conv, bn, relu=False, residual=None, training=False):
-    return ops().conv_bn_act(x, conv, bn, relu, residual, training)
-
-
-def head_out(x, conv, softplus=False):
-    return ops().head_out(x, conv, softplus)
-
-
-def window_block(x, blk, heads, scale1=None, scale2=None):
-    return ops().window_block(x, blk, heads, scale1, scale2)
-
-
-def exchange(xs, fuse, training, n_out=None):
-    return ops().exchange(xs, fuse, training, n_out)
-
-
-def drop_scales(n_draws, batch, drop_prob, device):
-    return nnops.drop_scales(n_draws, batch, drop_prob, device)
+# the network ops themselves (they refuse to run outside a scope: nnops._wc() raises without an active weight cache)
+from .nnops import conv_bn_act, drop_scales, exchange, head_out, to_features, window_block  # noqa: E402,F401
 
 
 def to_public(x):
@@ -263,6 +243,11 @@ def parallel(fns, inputs):
         counts = [len(x) for x in inputs]
         flat = [t for x in inputs for t in x]
         return list(_Region.apply(fns, counts, *flat))
+    if torch.is_grad_enabled() and torch.cuda.is_current_stream_capturing():
+        # Capturing the eager multi-stream schedule makes autograd insert direct side-stream <-> side-stream event edges in
+        # backward, and hipStreamEndCapture segfaults on them (ROCm 7.2; bisected in scripts/gpu_graph_streams.py).
+        raise PoseKernelError("hipGraph capture with concurrent branch streams needs region mode: call dispatch.set_region_mode(True) "
+                              "(engine.Trainer(graph_streams=True) does) or dispatch.set_streams(False) before capturing")
     cur = torch.cuda.current_stream()
     outs = [None] * n
     side = [None] + [_side_stream(cur.device, i) for i in range(1, n)]

@@ -68,6 +68,7 @@ class FlatAdamW:
         self.flags = flags.to(dev)
         self.active = [True] * len(self.params)
         self._grads_installed = False
+        self._sinks_armed = False          # True once a whole step has run with the gradient sinks installed
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.lr_dev = torch.full((1,), lr, dtype=torch.float32, device=dev)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -107,6 +108,8 @@ class FlatAdamW:
         if self._grads_installed:
             if not self.direct_grads:          # with the gradient sink every active gradient is overwritten, not accumulated
                 self.grad.zero_()
+            else:
+                nnops.begin_grad_epoch()       # a sink may be stored to once per epoch (checked in nnops.grad_sink_of)
         else:
             for p in self.params:
                 p.grad = None
@@ -121,6 +124,13 @@ class FlatAdamW:
             nnops.finalize_deferred()          # postponed parameter-gradient reductions (no-op when the Trainer already ran them)
         if not self._grads_installed:
             self.install_grad_views()
+        elif self.direct_grads and self._sinks_armed:
+            # direct-store sinks are not zeroed between steps: an active parameter whose sink no backward kernel asked for in
+            # this step (a batch that skipped a branch) must not have last step's gradient applied again
+            for i, p in enumerate(self.params):
+                if self.active[i] and not nnops.sink_written(p):
+                    self.grad_view(i).zero_()
+        self._sinks_armed = self.direct_grads
         self.step_count += 1
         self.step_dev.add_(1)
         hipops.adamw_step(self.flat, self.grad, self.exp_avg, self.exp_avg_sq, self.flags, None, self.lr_dev, self.step_dev,
@@ -370,6 +380,17 @@ class Trainer:
         self._graph.replay()
         if self._graph_has_opt:
             self.opt.step_count += 1          # the captured pk_adamw_step already advanced the device-side counter
+            # ... and rewrote the fp32 masters behind torch's back: the bf16 compute copies (and a padded twin's embedded
+            # parameters) are one step behind until the next forward repacks them
+            wc = getattr(self.model, "_pk_weight_cache", None)
+            if wc is not None:
+                wc.mark_dirty()
+            tw = getattr(self.model, "_pk_twin", None)
+            if tw:
+                tw.mark_dirty()
+                twc = getattr(tw.twin, "_pk_weight_cache", None)
+                if twc is not None:
+                    twc.mark_dirty()
         else:
             self.comm.finish()
             self.opt.step(self.comm.grad_scale)

@@ -219,6 +219,8 @@ class PaddedTwin:
     # ---- forward through the twin
     def run(self, *args, **kwargs):
         self.sync_to_twin()
+        if torch.is_grad_enabled():
+            nnops.begin_grad_epoch()             # the twin's gradient sinks are extracted after every backward and may be stored to again
         out = self.twin(*args, **kwargs)
         if self.real.training:
             self.buffers_to_real()

@@ -22,7 +22,6 @@ from ._lib import call, stream_ptr
 BF16, F32, I32 = torch.bfloat16, torch.float32, torch.int32
 ACT_DTYPE = BF16
 WS = 7
-IMPL = {"conv_bn_act": "hip", "window_block": "hip", "exchange": "hip", "head_out": "hip"}
 
 
 def _e(shape, dtype, dev):
@@ -32,12 +31,32 @@ def _e(shape, dtype, dev):
 # Gradient sink: a parameter may carry `_pk_grad_sink`, an fp32 view of the engine's flat gradient buffer.  Backward kernels
 # then store that parameter's gradient THERE (plain store: every parameter is used once per step) and hand None to autograd,
 # which removes ~800 `grad += g` launches per step.  Set by engine.FlatAdamW(direct_grads=True); absent = ordinary autograd.
+# The "once per step" assumption is checked: a step is delimited by `begin_grad_epoch()` (FlatAdamW.zero_grad), a second
+# request for the same sink inside one epoch raises (a plain store would silently drop the first gradient), and the optimiser
+# zeroes the sinks nobody asked for in the epoch (`sink_written`), so a stale gradient is never re-applied.
+_SINK_EPOCH = [0]
+
+
+def begin_grad_epoch():
+    _SINK_EPOCH[0] += 1
+
+
+def sink_written(param) -> bool:
+    """True when a backward kernel was handed this parameter's gradient sink since the last begin_grad_epoch()."""
+    return getattr(param, "_pk_epoch", -1) == _SINK_EPOCH[0]
+
+
 def grad_sink_of(param):
     """Called by backward functions only (and by the padded twin for the real parameters): a parameter whose sink was asked
     for has received a gradient this step (`_pk_used`; the padded twin extracts only those, others keep grad=None)."""
     dst = getattr(param, "_pk_grad_sink", None)
     if dst is not None:
+        if getattr(param, "_pk_epoch", -1) == _SINK_EPOCH[0] and _SINK_EPOCH[0] > 0:
+            raise _lib.PoseKernelError("gradient sink requested twice in one step: a parameter applied more than once per forward (or a "
+                                       "second backward without zero_grad) needs accumulation, which the direct-store sinks do not do; "
+                                       "build the optimiser with direct_grads=False")
         param._pk_used = True
+        param._pk_epoch = _SINK_EPOCH[0]
     return dst
 
 

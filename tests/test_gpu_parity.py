@@ -584,6 +584,55 @@ def test_graph_trainer_takes_an_odd_sized_batch_eagerly():
         dispatch.set_region_mode(False)
 
 
+def test_capture_with_streams_but_without_region_mode_raises():
+    """The combination that segfaulted hipStreamEndCapture in r01 (eager multi-stream autograd inside a capture) is refused
+    with an exception before any cross-stream edge is recorded."""
+    from infantposeestimation_gaussianbias_amd import _lib, dispatch
+    dispatch.set_streams(True)
+    dispatch.set_region_mode(False)
+    x = torch.ones(8, device=DEV, requires_grad=True)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with pytest.raises(_lib.PoseKernelError, match="region mode"):
+            with torch.cuda.graph(g, stream=s):
+                dispatch.parallel([lambda ins: ins[0] * 2, lambda ins: ins[0] * 3], [[x], [x]])
+    torch.cuda.synchronize()
+    assert float(dispatch.parallel([lambda ins: ins[0] * 2, lambda ins: ins[0] * 3], [[x], [x]])[1].sum()) == 24.0   # eager still works
+
+
+def test_eval_forward_between_graph_replays_sees_current_weights():
+    """The captured pk_adamw_step rewrites the fp32 masters on every replay; an eval forward after ANY replay must use bf16
+    copies packed from the current masters (they were one optimiser step behind from the second eval on)."""
+    from infantposeestimation_gaussianbias_amd import dispatch, engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import build_model
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    batch = synthetic_batch(4, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=9)
+    try:
+        torch.manual_seed(0)
+        model = build_model(cfg).to(DEV)
+        tr = engine.Trainer(model, cfg, iters_per_epoch=2, use_graph=True, graph_warmup=2, graph_streams=True)
+        for _ in range(4):
+            tr.step(batch)
+        assert tr._graph is not None
+        for _ in range(2):                                   # replay, eval, replay, eval
+            tr.step(batch)
+            with torch.no_grad():
+                got = model.eval()(batch["img"])["heatmaps"].clone()
+            fresh = build_model(cfg).to(DEV)
+            fresh.load_state_dict(model.state_dict())
+            with torch.no_grad():
+                ref = fresh.eval()(batch["img"])["heatmaps"]
+            assert torch.equal(got, ref)
+            model.train()
+    finally:
+        dispatch.set_region_mode(False)
+
+
 def test_deferred_reductions_match_inline_reductions(monkeypatch):
     """Parameter gradients with the slab reductions postponed to ONE pk_reduce_many launch equal the ones produced by the
     per-layer reduce kernels (same slabs; only LayerNorm / rel-pos-bias sums use a different fixed summation tree)."""
@@ -602,10 +651,13 @@ def test_deferred_reductions_match_inline_reductions(monkeypatch):
         model.backbone.drop_path_rate = 0.0
         tr = engine.Trainer(model, cfg, iters_per_epoch=2)
         tr._fwd_bwd(batch)
-        tr.opt.install_grad_views()           # gradient sinks from here on
+        tr.opt.install_grad_views()           # gradient sinks from here on (the views now hold the autograd-mode gradients)
+        auto = tr.opt.grad.clone()
         tr._fwd_bwd(batch)
         torch.cuda.synchronize()
         grads[defer] = tr.opt.grad.clone()
+        # sink-mode gradients (stored by the backward kernels) == autograd-mode gradients of the first pass
+        assert float((auto - grads[defer]).norm() / auto.norm()) < 1e-5
     a, b = grads["0"], grads["1"]
     assert float((a - b).abs().max() / a.abs().max()) < 1e-6
     names = [n for n, p, o in zip(tr.opt.names, tr.opt.params, tr.opt.offsets)

@@ -188,6 +188,28 @@ int pk_ln_bwd_blocks(int64_t rows);                          /* partial needs bl
 int pk_layernorm_bwd(const void* dy, const void* x, const float* save_mean, const float* save_rstd, const float* gamma,
                      const void* dresidual, void* dx, float* partial, float* dgamma, float* dbeta, int64_t rows, int C, int C_real,
                      void* stream);
+/* Fused MLP half of the HRFormer block (hrformer.py:288-291 with Mlp :38-64 and DropPath :15-35), C = 32 / 64:
+ *   y = x + row_scale[b] * ( fc2( gelu_erf( fc1( LayerNorm(x; gamma, beta, eps) ) + b1 ) ) + b2 )       x, y: [M][C] bf16
+ * ONE launch; the 4C-wide hidden activation stays in registers.  w1 = fc1.weight [4C][C] bf16, w2 = fc2.weight [C][4C] bf16
+ * (forward copies); w1_t = [C][4C], w2_t = [4C][C] (data-gradient copies).  row_scale (or NULL) is indexed by row / rows_per_sample.
+ * Backward recomputes LayerNorm / fc1 / GELU from x (nothing but x is saved):
+ *   pk_ln_mlp_bwd_dx: dx = dy + dLayerNorm(...), ln_partial[pk_ln_mlp_dx_blocks][2][C] = per-workgroup sums for dgamma | dbeta;
+ *   pk_ln_mlp_bwd_dw: slabs[(4C / HS) slices][pk_ln_mlp_dw_blocks][pk_ln_mlp_slab_floats] with HS = pk_ln_mlp_hidden_slice(C);
+ *                     one slab = [ dW1 rows h0..h0+HS [HS][C] | dW2 columns h0..h0+HS [C][HS] | db1[h0..] [HS] | db2 [C] ] fp32,
+ *                     to be summed over the workgroup index (pk_reduce_many layouts 0 / 2); db2 is complete in every slice.   */
+int pk_ln_mlp_supported(int C);
+int pk_ln_mlp_hidden_slice(int C);
+int pk_ln_mlp_slab_floats(int C);
+int pk_ln_mlp_dx_blocks(int M, int C);
+int pk_ln_mlp_dw_blocks(int M, int C);
+int pk_ln_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
+                  const float* b2, const float* row_scale, void* y, int M, int C, int rows_per_sample, float eps, void* stream);
+int pk_ln_mlp_bwd_dx(const void* dy, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
+                     const void* w1_t, const void* w2_t, const float* row_scale, void* dx, float* ln_partial, int M, int C,
+                     int rows_per_sample, float eps, void* stream);
+int pk_ln_mlp_bwd_dw(const void* dy, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
+                     const void* w2_t, const float* row_scale, float* slabs, int M, int C, int rows_per_sample, float eps,
+                     void* stream);
 int pk_colsum_bf16(const void* g, const int32_t* rowmap, const float* row_scale, int rows_per_sample, float* partial,
                    float* out, int64_t rows, int N, void* stream);
 /* exchange unit sum (hrformer.py:471-489 == hrnet.py:207-225): out = relu?(sum_i bilinear_up_i(x_i)), F.interpolate
@@ -202,7 +224,7 @@ int pk_nchw_f32_to_nhwc_bf16(const float* x, const float* softplus_out, void* y,
  * mode 0: dst[n][t][cp]=src[n][c][t] (forward), 1: dst[c][T-1-t][np]=src[n][c][t] (conv data-grad), 2: dst[c][np]=src[n][c] */
 /* Deferred parameter-gradient reductions: ONE launch for any number of slab sums  out[index(i)] = sum_{s<S} part[s*slab_stride + i], i < K.
  * desc_table rows (56 bytes): { const float* part; float* out; int64 slab_stride; int S, K, layout, N, T, Cin, out_stride, pad; };
- * layout 0: index(i) = i*out_stride; layout 1: i = (n*T + t)*Cin + c -> OIHW (n*Cin + c)*T + t.  One 256-thread block per 64
+ * layout 0: index(i) = i*out_stride; layout 1: i = (n*T + t)*Cin + c -> OIHW (n*Cin + c)*T + t; layout 2: i = a*Cin + b -> a*T + b*out_stride.  One 256-thread block per 64
  * outputs (block_desc = row, block_first = first block of that row).  Producers: pk_wgrad_bf16 (dw NULL), pk_layernorm_bwd
  * (dgamma/dbeta NULL: partial is [blocks][2C]), pk_window_attn_bwd (dtable NULL: partial is [groups][169]).                   */
 int pk_reduce_many(const void* desc_table, const int* block_desc, const int* block_first, int n_blocks, void* stream);

@@ -80,3 +80,29 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f) { return __builtin_bit_
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector((pk_f32x2){lo, hi}, pk_bf16x2));
 }
+
+// ---- GELU (exact-erf form) shared by the GEMM epilogues and the fused block kernels ---------------------------
+// erf via Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at fp32 rounding level and 4 orders of magnitude below the
+// bf16 rounding of every tensor these activations are stored to): one v_rcp, one v_exp, five FMAs.  libm's erff inlines
+// to ~60 instructions with a divergent branch, and the epilogue evaluates it for every element of the MLP hidden layer.
+// `e` = exp(-x*x) is passed in because GELU's derivative needs the same exponential.
+__device__ __forceinline__ float erf_as(float x, float e) {
+    const float ax = fabsf(x);
+    const float t = __frcp_rn(__fmaf_rn(0.3275911f, ax, 1.f));
+    float q = __fmaf_rn(1.061405429f, t, -1.453152027f);
+    q = __fmaf_rn(q, t, 1.421413741f);
+    q = __fmaf_rn(q, t, -0.284496736f);
+    q = __fmaf_rn(q, t, 0.254829592f);
+    const float r = 1.f - q * t * e;
+    return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_erf(float v) {
+    const float e = __expf(-0.5f * v * v);
+    return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f, e));
+}
+__device__ __forceinline__ float softplus_(float v) { return v > 20.f ? v : log1pf(__expf(v)); }
+__device__ __forceinline__ float gelu_grad(float z) {
+    const float e = __expf(-0.5f * z * z);
+    return 0.5f * (1.f + erf_as(z * 0.70710678118654752440f, e)) + z * 0.39894228040143267794f * e;
+}
+

@@ -49,30 +49,6 @@ struct IgemmArgs {
     int vec8;                 // set by igemm_launch: row-major pointers 16-byte aligned and ldo % 8 == 0 -> 16-byte epilogue I/O
 };
 
-// erf via Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at fp32 rounding level and 4 orders of magnitude below the
-// bf16 rounding of every tensor these activations are stored to): one v_rcp, one v_exp, five FMAs.  libm's erff inlines
-// to ~60 instructions with a divergent branch, and the epilogue evaluates it for every element of the MLP hidden layer.
-// `e` = exp(-x*x) is passed in because GELU's derivative needs the same exponential.
-__device__ __forceinline__ float erf_as(float x, float e) {
-    const float ax = fabsf(x);
-    const float t = __frcp_rn(__fmaf_rn(0.3275911f, ax, 1.f));
-    float q = __fmaf_rn(1.061405429f, t, -1.453152027f);
-    q = __fmaf_rn(q, t, 1.421413741f);
-    q = __fmaf_rn(q, t, -0.284496736f);
-    q = __fmaf_rn(q, t, 0.254829592f);
-    const float r = 1.f - q * t * e;
-    return copysignf(r, x);
-}
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float e = __expf(-0.5f * v * v);
-    return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f, e));
-}
-__device__ __forceinline__ float softplus_(float v) { return v > 20.f ? v : log1pf(__expf(v)); }
-__device__ __forceinline__ float gelu_grad(float z) {
-    const float e = __expf(-0.5f * z * z);
-    return 0.5f * (1.f + erf_as(z * 0.70710678118654752440f, e)) + z * 0.39894228040143267794f * e;
-}
-
 // ================================================================================================ main kernel (v2)
 // Same contraction and epilogue as above, restructured so the K loop is MFMA-bound instead of issue-bound:
 //   * filter taps are the OUTER loop: per tap each thread computes ONE byte offset per staged row (bounds, dilation);
@@ -867,7 +843,8 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 // the data-gradient chain (~360 of the ~2 000 launches per step, each 6-12 us plus the dependency bubble around it).  With
 // dw/dgamma/dtable == NULL the producers only write their slabs; ONE table-driven launch at the end of backward reduces
 // them all:   out[index(i)] = sum_{s < S} part[s * slab_stride + i],  i < K
-//   layout 0: index(i) = i * out_stride;   layout 1 (conv OIHW): i = (n*T + t)*Cin + c  ->  (n*Cin + c)*T + t.
+//   layout 0: index(i) = i * out_stride;   layout 1 (conv OIHW): i = (n*T + t)*Cin + c  ->  (n*Cin + c)*T + t;
+//   layout 2 (2-D slice): i = a*Cin + b  ->  a*T + b*out_stride  (a column block of a wider row-major matrix).
 // Fixed-order combine (deterministic).
 struct ReduceDesc { const float* part; float* out; int64_t slab_stride; int S, K, layout, N, T, Cin, out_stride, pad_; };
 // Block = 64 outputs (16 groups of 4 consecutive) x 16 slab-lanes: 16-byte loads, 256 contiguous bytes per slab row and block
@@ -911,6 +888,7 @@ __global__ void __launch_bounds__(256) k_reduce_many(const ReduceDesc* __restric
         const int ij = i + j;
         if (ij >= d.K) break;
         if (d.layout == 0) d.out[(size_t)ij * d.out_stride] = o4[j];
+        else if (d.layout == 2) d.out[(size_t)(ij / d.Cin) * d.T + (size_t)(ij % d.Cin) * d.out_stride] = o4[j];   // 2-D: [a][b < Cin] -> a*T + b*out_stride
         else {
             const int c = ij % d.Cin, t = (ij / d.Cin) % d.T, n = ij / (d.Cin * d.T);
             d.out[((size_t)n * d.Cin + c) * d.T + t] = o4[j];

@@ -121,6 +121,18 @@ def _defer(part_ptr, out, slab_stride, S, K, layout=0, N=0, T=1, Cin=1, out_stri
     _PENDING.append((part_ptr, out.data_ptr() + 4 * out_offset, slab_stride, S, K, layout, N, T, Cin, out_stride, 0))
 
 
+def _reduce_table(key, dev):
+    desc = np.array(list(key), dtype=_REDUCE_DTYPE)
+    blk_desc, blk_first, nb = [], [], 0
+    for i, r in enumerate(key):
+        k = -(-r[4] // 64)
+        blk_desc += [i] * k
+        blk_first += [nb] * k
+        nb += k
+    return dict(desc=torch.from_numpy(desc.view(np.uint8)).to(dev), nb=nb, blk_desc=torch.tensor(blk_desc, dtype=I32, device=dev),
+                blk_first=torch.tensor(blk_first, dtype=I32, device=dev))
+
+
 def finalize_deferred():
     """Reduce every slab set registered since the last call (no-op when nothing is pending)."""
     if not _PENDING:
@@ -132,18 +144,17 @@ def finalize_deferred():
         if torch.cuda.is_current_stream_capturing():
             raise _lib.PoseKernelError("deferred-reduction table changed during hipGraph capture (host->device table upload is not "
                                        "capturable): run at least two eager warm-up steps before capturing")
-        dev = torch.device("cuda", torch.cuda.current_device())
-        desc = np.array(list(key), dtype=_REDUCE_DTYPE)
-        blk_desc, blk_first, nb = [], [], 0
-        for i, r in enumerate(key):
-            k = -(-r[4] // 64)
-            blk_desc += [i] * k
-            blk_first += [nb] * k
-            nb += k
-        tab = _TABLES[key] = dict(desc=torch.from_numpy(desc.view(np.uint8)).to(dev), nb=nb,
-                                  blk_desc=torch.tensor(blk_desc, dtype=I32, device=dev),
-                                  blk_first=torch.tensor(blk_first, dtype=I32, device=dev))
+        tab = _TABLES[key] = _reduce_table(key, torch.device("cuda", torch.cuda.current_device()))
     call("pk_reduce_many", tab["desc"], tab["blk_desc"], tab["blk_first"], tab["nb"], stream_ptr())
+
+
+def _reduce_now(rows, dev):
+    """Slab sums whose destinations are ordinary tensors (no gradient sink): one uncached pk_reduce_many launch."""
+    tab = _reduce_table(tuple(rows), dev)
+    call("pk_reduce_many", tab["desc"], tab["blk_desc"], tab["blk_first"], tab["nb"], stream_ptr())
+    for t in tab.values():                      # keep the table alive until the launch has consumed it
+        if torch.is_tensor(t):
+            t.record_stream(torch.cuda.current_stream())
 
 
 # ================================================================================================ weight cache
@@ -595,12 +606,80 @@ class _MlpHalf(torch.autograd.Function):
                 None if s_b2 else db2, None, None)
 
 
+def fused_mlp_enabled(C, c_real=0):
+    import os
+    return c_real in (0, C) and os.environ.get("POSE_FUSED_MLP", "1") != "0" and bool(_lib.lib.pk_ln_mlp_supported(C))
+
+
+class _MlpHalfFused(torch.autograd.Function):
+    """x + s2 * fc2(gelu(fc1(LN2(x)))) as ONE launch (pk_ln_mlp_fwd, C = 32 / 64): the 4C hidden never reaches HBM and nothing but
+    x is saved; backward = pk_ln_mlp_bwd_dx (dx + LayerNorm partials) and pk_ln_mlp_bwd_dw (weight / bias slabs), both
+    recomputing the hidden from x."""
+
+    @staticmethod
+    def forward(ctx, x, g2, b2, w1, bias1, w2, bias2, scale2):
+        ctx.params = (g2, b2, w1, bias1, w2, bias2)
+        wc = _wc()
+        x = x.contiguous()
+        B, H, W, C = x.shape
+        M = B * H * W
+        s2 = None if scale2 is None else scale2.float().contiguous()
+        y = _e((B, H, W, C), BF16, x.device)
+        call("pk_ln_mlp_fwd", x, g2, b2, wc.fwd[id(w1)], bias1, wc.fwd[id(w2)], bias2, s2, y, M, C, H * W, 1e-5, stream_ptr())
+        ctx.save_for_backward(x, g2, b2, bias1, s2 if s2 is not None else x.new_empty(0), wc.fwd[id(w1)], wc.dgrad[id(w1)], wc.dgrad[id(w2)])
+        ctx.meta = (B, H, W, C, s2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g2, b2, bias1, s2, w1f, w1t, w2t = ctx.saved_tensors
+        B, H, W, C, has_s = ctx.meta
+        s2 = s2 if has_s else None
+        M, Hd, dev = B * H * W, 4 * C, dy.device
+        dy = dy.contiguous()
+        pg2, pb2, pw1, pbias1, pw2, pbias2 = ctx.params
+        (dg, sg), (db, sb) = _sink(pg2), _sink(pb2)
+        (dw1, s_w1), (db1, s_b1), (dw2, s_w2), (dbb2, s_b2) = _sink(pw1), _sink(pbias1), _sink(pw2), _sink(pbias2)
+        all_sinks = sg and sb and s_w1 and s_b1 and s_w2 and s_b2 and deferral_enabled()
+        nbx, nbw = _lib.lib.pk_ln_mlp_dx_blocks(M, C), _lib.lib.pk_ln_mlp_dw_blocks(M, C)
+        HS, SL = _lib.lib.pk_ln_mlp_hidden_slice(C), _lib.lib.pk_ln_mlp_slab_floats(C)
+        ns = Hd // HS
+        if all_sinks:
+            lnp, slabs = _workspace(dg, "mlp_ln", nbx * 2 * C), _workspace(dw1, "mlp_w", ns * nbw * SL)
+        else:
+            lnp, slabs = _e((nbx * 2 * C,), F32, dev), _e((ns * nbw * SL,), F32, dev)
+        dx = _e((B, H, W, C), BF16, dev)
+        call("pk_ln_mlp_bwd_dx", dy, x, g2, b2, w1f, bias1, w1t, w2t, s2, dx, lnp, M, C, H * W, 1e-5, stream_ptr())
+        call("pk_ln_mlp_bwd_dw", dy, x, g2, b2, w1f, bias1, w2t, s2, slabs, M, C, H * W, 1e-5, stream_ptr())
+        rows = []
+
+        def red(part_off, out, S, K, stride, layout=0, T=1, Cin=1, out_stride=1, out_offset=0, base=slabs):
+            rows.append((base.data_ptr() + 4 * part_off, out.data_ptr() + 4 * out_offset, stride, S, K, layout, 0, T, Cin, out_stride, 0))
+
+        red(0, dg, nbx, C, 2 * C, base=lnp)
+        red(C, db, nbx, C, 2 * C, base=lnp)
+        for y in range(ns):
+            o = y * nbw * SL
+            red(o, dw1, nbw, HS * C, SL, out_offset=y * HS * C)                                          # rows h0 .. h0+HS of [4C][C]
+            red(o + HS * C, dw2, nbw, C * HS, SL, layout=2, T=Hd, Cin=HS, out_stride=1, out_offset=y * HS)   # columns h0 .. of [C][4C]
+            red(o + 2 * HS * C, db1, nbw, HS, SL, out_offset=y * HS)
+        red(2 * HS * C + HS, dbb2, nbw, C, SL)
+        if all_sinks:
+            _PENDING.extend(rows)
+            return dx, None, None, None, None, None, None, None
+        _reduce_now(rows, dev)
+        return (dx, None if sg else dg, None if sb else db, None if s_w1 else dw1, None if s_b1 else db1, None if s_w2 else dw2,
+                None if s_b2 else dbb2, None)
+
+
 def window_block(x, blk, heads, scale1=None, scale2=None):
     a = blk.attn
     c_real, attn_scale = getattr(blk, "c_real", 0), getattr(blk, "attn_scale", 0.0)      # set on padded twins (models/padded.py)
     x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
                         a.proj.weight, a.proj.bias, scale1, heads, c_real, attn_scale)
     m = blk.mlp
+    if fused_mlp_enabled(x.shape[-1], c_real) and m.fc1.weight.shape[0] == 4 * x.shape[-1]:
+        return _MlpHalfFused.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2)
     return _MlpHalf.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2, c_real)
 
 

@@ -132,6 +132,57 @@ def elementwise_cases(flt):
         report(name, sec, None, 2 * M * Cc * 2)
 
 
+def block_cases(flt):
+    """HRFormer block halves at the four branch shapes of HRFormer-small (B = 64): fused kernels vs the unfused sequences.
+    Algorithmic bytes: forward reads x and writes y (4C B/token); backward reads x, dy and writes dx (6C B/token)."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    for (H, W, C, heads) in [(64, 48, 32, 1), (32, 24, 64, 2), (16, 12, 128, 4), (8, 6, 256, 8)]:
+        name = f"block C={C} @{H}x{W}"
+        if flt and flt not in name:
+            continue
+        B = 64
+        blk = HRFormerBlock(C, heads).to(DEV)
+        x = torch.randn(B, H, W, C, device=DEV).to(BF).requires_grad_(True)
+        gy = torch.randn(B, H, W, C, device=DEV).to(BF)
+        s2 = torch.ones(B, device=DEV)
+        M = B * H * W
+        m = blk.mlp
+        margs = (blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, s2)
+        with nnops.use_weights(blk) as wc:
+            variants = [("mlp unfused", lambda: nnops._MlpHalf.apply(x, *margs, 0))]
+            if nnops.fused_mlp_enabled(C):
+                variants.append(("mlp FUSED", lambda: nnops._MlpHalfFused.apply(x, *margs)))
+            for tag, fn in variants:
+                with torch.no_grad():
+                    sec = timeit(fn)
+                report(f"{name} {tag} fwd", sec, 16.0 * M * C * C, 4 * M * C)
+                y = fn()
+                sec = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True))
+                report(f"{name} {tag} bwd (all launches)", sec, 32.0 * M * C * C, 6 * M * C)
+            if nnops.fused_mlp_enabled(C):
+                w1f, w1t, w2t = wc.fwd[id(m.fc1.weight)], wc.dgrad[id(m.fc1.weight)], wc.dgrad[id(m.fc2.weight)]
+                dx = torch.empty_like(x)
+                lnp = torch.empty(lib.pk_ln_mlp_dx_blocks(M, C) * 2 * C, device=DEV)
+                slabs = torch.empty((4 * C // lib.pk_ln_mlp_hidden_slice(C)) * lib.pk_ln_mlp_dw_blocks(M, C) * lib.pk_ln_mlp_slab_floats(C), device=DEV)
+                xd = x.detach()
+                sec = timeit(lambda: call("pk_ln_mlp_bwd_dx", gy, xd, blk.norm2.weight, blk.norm2.bias, w1f, m.fc1.bias, w1t, w2t, s2, dx, lnp,
+                                          M, C, H * W, 1e-5, stream_ptr()))
+                report(f"{name} mlp FUSED bwd_dx kernel", sec, 24.0 * M * C * C, 6 * M * C)
+                sec = timeit(lambda: call("pk_ln_mlp_bwd_dw", gy, xd, blk.norm2.weight, blk.norm2.bias, w1f, m.fc1.bias, w2t, s2, slabs,
+                                          M, C, H * W, 1e-5, stream_ptr()))
+                report(f"{name} mlp FUSED bwd_dw kernel", sec, 32.0 * M * C * C, 4 * M * C + slabs.numel() * 4)
+            a = blk.attn
+            aargs = (blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
+                     s2, heads)
+            fn = lambda: nnops._AttnHalf.apply(x, *aargs)
+            with torch.no_grad():
+                sec = timeit(fn)
+            report(f"{name} attn unfused fwd", sec, None, 4 * M * C)
+            y = fn()
+            sec = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True))
+            report(f"{name} attn unfused bwd (all launches)", sec, None, 6 * M * C)
+
+
 if __name__ == "__main__":
     flt = sys.argv[1] if len(sys.argv) > 1 else None
     print(torch.cuda.get_device_name(0))
@@ -139,3 +190,4 @@ if __name__ == "__main__":
     linear_cases(flt)
     attn_cases(flt)
     elementwise_cases(flt)
+    block_cases(flt)

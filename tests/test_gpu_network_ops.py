@@ -522,3 +522,62 @@ def test_exchange_unit_vs_oracle(N):
     bad = {k: v for k, v in report.items() if v > (2e-2 if k[0] == "y" else 0.35)}
     bad.update({"l2:" + k: v for k, v in l2.items() if v > 0.1})     # train-mode BN over 24-384 samples: ill-conditioned
     assert not bad, bad
+
+
+# ------------------------------------------------------------------------------------------------ fused MLP half (C = 32 / 64)
+def _mlp_half_reference(x, blk, s2):
+    """fp32 torch reference of x + s2 * fc2(gelu(fc1(LN2(x)))) on (B,H,W,C) (hrformer.py:288-291), LN output rounded to bf16 like the
+    kernel's MFMA operand, hidden activation rounded to bf16 like the second MFMA's operand."""
+    v = q(F.layer_norm(x, (x.shape[-1],), blk.norm2.weight, blk.norm2.bias, 1e-5))
+    h = F.gelu(v @ blk.mlp.fc1.weight.T + blk.mlp.fc1.bias)
+    m = h @ blk.mlp.fc2.weight.T + blk.mlp.fc2.bias
+    return x + (m if s2 is None else m * s2.view(-1, 1, 1, 1))
+
+
+@pytest.mark.parametrize("Cc,B,H,W,scaled", [(32, 3, 9, 10, True), (32, 2, 64, 48, False), (64, 3, 5, 7, True), (64, 2, 32, 24, False),
+                                             (32, 1, 1, 5, True), (64, 5, 16, 12, True)])
+def test_fused_mlp_half_vs_torch_and_unfused(N, monkeypatch, Cc, B, H, W, scaled):
+    """pk_ln_mlp_fwd / _bwd_dx / _bwd_dw (one forward launch, hidden activation never in HBM, backward recomputes) against a
+    plain fp32 PyTorch reference of the same half: forward 8e-3 (bf16 store), dx 1e-2, parameter gradients 1e-2 norm-wise; and
+    against the unfused kernel sequence (LN, fc1+GELU, fc2 GEMMs), which rounds at more places: 2e-2."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    torch.manual_seed(Cc + H)
+    blk = HRFormerBlock(Cc, Cc // 32)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            p.copy_(q(p * 4) if p.dim() > 1 else q(p + 0.1 * torch.randn_like(p)))
+    x = q(torch.randn(B, H, W, Cc, generator=torch.Generator().manual_seed(1)) * 1.5)
+    gy = q(torch.randn(B, H, W, Cc, generator=torch.Generator().manual_seed(2)))
+    s2 = torch.tensor([0.0, 1 / 0.9, 1 / 0.9, 1 / 0.9, 0.0][:B]) if scaled else None
+    xr = x.clone().requires_grad_(True)
+    y_ref = _mlp_half_reference(xr, blk, s2)
+    y_ref.backward(gy)
+    ref_g = {k: p.grad.clone() for k, p in blk.named_parameters() if p.grad is not None}
+    blk.zero_grad()
+    blk = blk.to(DEV)
+    m = blk.mlp
+    args = lambda: (blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, None if s2 is None else s2.to(DEV))
+    out = {}
+    for mode in ("fused", "unfused"):
+        for p in blk.parameters():
+            p.grad = None
+        xd = x.to(DEV, BF).requires_grad_(True)
+        with N.use_weights(blk):
+            y = N._MlpHalfFused.apply(xd, *args()) if mode == "fused" else N._MlpHalf.apply(xd, *args(), 0)
+            y.backward(gy.to(DEV, BF))
+        torch.cuda.synchronize()
+        out[mode] = (C(y), C(xd.grad), {k: C(p.grad) for k, p in blk.named_parameters() if p.grad is not None})
+    y, gx, gp = out["fused"]
+    rep = {"y": err(y, y_ref.detach()), "gx": err(gx, xr.grad)}
+    for k in ref_g:
+        rep["g." + k] = err(gp[k], ref_g[k])
+    print("fused vs fp32", {k: round(v, 5) for k, v in rep.items()})
+    assert rep["y"] < 8e-3 and rep["gx"] < 1e-2, rep
+    assert set(gp) == set(ref_g) == {"norm2.weight", "norm2.bias", "mlp.fc1.weight", "mlp.fc1.bias", "mlp.fc2.weight", "mlp.fc2.bias"}
+    assert all(v < 1e-2 for k, v in rep.items() if k.startswith("g.")), rep
+    yu, gxu, gpu_ = out["unfused"]
+    assert err(y, yu) < 2e-2 and err(gx, gxu) < 2e-2
+    for k in gp:
+        assert err(gp[k], gpu_[k]) < 2e-2, k
+    if s2 is not None:      # dropped samples: the half is the identity, their tokens contribute nothing to the MLP's gradients
+        assert torch.equal(y[0], x[0].to(BF).float()) and torch.equal(gx[0], gy[0].to(BF).float())

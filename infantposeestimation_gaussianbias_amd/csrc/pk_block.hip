@@ -511,11 +511,10 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dw(MlpArgs p) {
                     f32x4 hh, dz;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        // gelu and gelu' share the exponential and the erf polynomial
-                        const float zz = z[rt][r], e = __expf(-0.5f * zz * zz);
-                        const float cdf = 0.5f * (1.f + erf_as(zz * 0.70710678118654752440f, e));
-                        hh[r] = zz * cdf;
-                        dz[r] = dh[rt][r] * (cdf + zz * 0.39894228040143267794f * e);
+                        float gv, gd;                       // gelu and gelu' share the exponential and the erf polynomial
+                        gelu_both(z[rt][r], gv, gd);
+                        hh[r] = gv;
+                        dz[r] = dh[rt][r] * gd;
                     }
                     *reinterpret_cast<u32x2*>(tH + (16 * rt + i16) * PH + 16 * u + 4 * g) = pack4(hh);
                     *reinterpret_cast<u32x2*>(tD + (16 * rt + i16) * PH + 16 * u + 4 * g) = pack4(dz);
@@ -579,7 +578,13 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dw(MlpArgs p) {
 }
 
 // ================================================================================================ C-ABI
-static inline int mlp_hidden_slice(int C) { return C == 32 ? 128 : 64; }          // HS * C = 4096 accumulator floats per matrix
+static inline int mlp_hidden_slice(int C) {          // hidden units per blockIdx.y slice of the weight-gradient kernel
+    static const int env = getenv("PK_MLP_HS") ? atoi(getenv("PK_MLP_HS")) : 0;
+    if (env == 32 || env == 64 || (env == 128 && C == 32)) return env;
+    // Measured (B = 64): the 128 accumulator registers of HS * C = 4096 hold the kernel at one wave per SIMD (C = 32: 66 us);
+    // half of that (two waves per SIMD) runs the same work in 40 us although every slice recomputes LayerNorm.
+    return C == 32 ? 64 : 32;
+}
 static inline int mlp_row_groups(int M) { return (M + 31) / 32; }
 extern "C" int pk_ln_mlp_supported(int C) { return C == 32 || C == 64; }
 extern "C" int pk_ln_mlp_hidden_slice(int C) { return mlp_hidden_slice(C); }
@@ -589,11 +594,16 @@ extern "C" int pk_ln_mlp_slab_floats(int C) {
 }
 // workgroups (4 waves, one 32-token group per wave and iteration): enough to fill 256 CUs twice, never more than the work
 static inline int mlp_blocks(int M, int target) {
+    static const int env_target = getenv("PK_MLP_WGS") ? atoi(getenv("PK_MLP_WGS")) : 0;
+    if (env_target > 0) target = env_target;
     const int need = (mlp_row_groups(M) + 3) / 4;
     return need < target ? (need < 1 ? 1 : need) : target;
 }
 extern "C" int pk_ln_mlp_dx_blocks(int M, int C) { return mlp_blocks(M, 512); }
-extern "C" int pk_ln_mlp_dw_blocks(int M, int C) { return mlp_blocks(M, 512 / ((4 * C) / mlp_hidden_slice(C))); }
+// (fewer, longer-lived workgroups: each one stages its weight slice and ends with a 4-phase slab reduction; 256 x slices
+// workgroups beat 512 and 1024 at every slice width)
+// workgroups beat 512 and 1024 at every slice width; C = 64 with its 8 slices: 64 x 8 = 38 us, 128 x 8 = 46 us, 256 x 8 = 67 us)
+extern "C" int pk_ln_mlp_dw_blocks(int M, int C) { return mlp_blocks(M, C == 32 ? 256 : 64); }
 
 static int mlp_check(const char* who, const MlpArgs& a, int C) {
     PK_SUPPORTED(C == 32 || C == 64, "%s: C=%d (the fused MLP half is built for C = 32 / 64)", who, C);
@@ -645,8 +655,13 @@ extern "C" int pk_ln_mlp_bwd_dw(const void* dy, const void* x, const float* gamm
     int rc = mlp_check("pk_ln_mlp_bwd_dw", a, C);
     if (rc) return rc;
     PK_REQUIRE(dy && w1 && w2_t && slabs, "pk_ln_mlp_bwd_dw: null pointer");
-    const dim3 grid(pk_ln_mlp_dw_blocks(M, C), (4 * C) / mlp_hidden_slice(C)), block(256);
-    if (C == 32) hipLaunchKernelGGL((k_mlp_bwd_dw<32, 128>), grid, block, 0, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL((k_mlp_bwd_dw<64, 64>), grid, block, 0, (hipStream_t)stream, a);
+    const int hs = mlp_hidden_slice(C);
+    const dim3 grid(pk_ln_mlp_dw_blocks(M, C), (4 * C) / hs), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    if (C == 32 && hs == 128) hipLaunchKernelGGL((k_mlp_bwd_dw<32, 128>), grid, block, 0, st, a);
+    else if (C == 32 && hs == 64) hipLaunchKernelGGL((k_mlp_bwd_dw<32, 64>), grid, block, 0, st, a);
+    else if (C == 32) hipLaunchKernelGGL((k_mlp_bwd_dw<32, 32>), grid, block, 0, st, a);
+    else if (hs == 64) hipLaunchKernelGGL((k_mlp_bwd_dw<64, 64>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_mlp_bwd_dw<64, 32>), grid, block, 0, st, a);
     return pk_launch_status("pk_ln_mlp_bwd_dw");
 }

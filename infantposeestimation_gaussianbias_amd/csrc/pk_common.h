@@ -82,27 +82,38 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 }
 
 // ---- GELU (exact-erf form) shared by the GEMM epilogues and the fused block kernels ---------------------------
-// erf via Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, i.e. at fp32 rounding level and 4 orders of magnitude below the
-// bf16 rounding of every tensor these activations are stored to): one v_rcp, one v_exp, five FMAs.  libm's erff inlines
-// to ~60 instructions with a divergent branch, and the epilogue evaluates it for every element of the MLP hidden layer.
-// `e` = exp(-x*x) is passed in because GELU's derivative needs the same exponential.
-__device__ __forceinline__ float erf_as(float x, float e) {
+// Phi(x) = 0.5 (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7: fp32 rounding level, four
+// orders of magnitude below the bf16 rounding of every tensor these activations are stored to).  Written for instruction
+// count -- the fused MLP kernels are VALU-bound on exactly this code (25 M hidden elements per block at B = 64):
+//   hw(x) = 0.5 (1 - erf(|x| / sqrt 2)) = t (a1' + t (a2' + ...)) exp(-x^2 / 2),  t = 1 / (1 + p |x| / sqrt 2),  a' = a / 2
+//   gelu(x)  = max(x, 0) - |x| hw          (x >= 0: x (1 - hw);  x < 0: x hw)
+//   gelu'(x) = Phi(x) + x exp(-x^2/2) / sqrt(2 pi),   Phi = x >= 0 ? 1 - hw : hw
+// 1 v_rcp + 1 v_exp + 11 (gelu) / 14 (gelu') plain VALU ops.  (libm erff is ~60 instructions with a divergent branch; the first
+// version of this code used __frcp_rn, which hipcc expands to a correctly rounded division: 10 instructions instead of one.)
+struct GeluTerms { float hw, e; };
+__device__ __forceinline__ GeluTerms gelu_terms(float x) {
     const float ax = fabsf(x);
-    const float t = __frcp_rn(__fmaf_rn(0.3275911f, ax, 1.f));
-    float q = __fmaf_rn(1.061405429f, t, -1.453152027f);
-    q = __fmaf_rn(q, t, 1.421413741f);
-    q = __fmaf_rn(q, t, -0.284496736f);
-    q = __fmaf_rn(q, t, 0.254829592f);
-    const float r = 1.f - q * t * e;
-    return copysignf(r, x);
+    const float t = __builtin_amdgcn_rcpf(__fmaf_rn(0.3275911f * 0.70710678118654752440f, ax, 1.f));
+    float q = __fmaf_rn(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+    q = __fmaf_rn(q, t, 0.5f * 1.421413741f);
+    q = __fmaf_rn(q, t, 0.5f * -0.284496736f);
+    q = __fmaf_rn(q, t, 0.5f * 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.44269504088896340736f));
+    return GeluTerms{(q * t) * e, e};
 }
-__device__ __forceinline__ float gelu_erf(float v) {
-    const float e = __expf(-0.5f * v * v);
-    return 0.5f * v * (1.f + erf_as(v * 0.70710678118654752440f, e));
+__device__ __forceinline__ float gelu_erf(float x) {
+    const GeluTerms g = gelu_terms(x);
+    return __fmaf_rn(-fabsf(x), g.hw, fmaxf(x, 0.f));
+}
+__device__ __forceinline__ float gelu_cdf(float x, float hw) { return 0.5f + copysignf(0.5f - hw, x); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    const GeluTerms g = gelu_terms(x);
+    return __fmaf_rn(x * 0.39894228040143267794f, g.e, gelu_cdf(x, g.hw));
+}
+// value and derivative from one evaluation of the shared terms
+__device__ __forceinline__ void gelu_both(float x, float& val, float& grad) {
+    const GeluTerms g = gelu_terms(x);
+    val = __fmaf_rn(-fabsf(x), g.hw, fmaxf(x, 0.f));
+    grad = __fmaf_rn(x * 0.39894228040143267794f, g.e, gelu_cdf(x, g.hw));
 }
 __device__ __forceinline__ float softplus_(float v) { return v > 20.f ? v : log1pf(__expf(v)); }
-__device__ __forceinline__ float gelu_grad(float z) {
-    const float e = __expf(-0.5f * z * z);
-    return 0.5f * (1.f + erf_as(z * 0.70710678118654752440f, e)) + z * 0.39894228040143267794f * e;
-}
-

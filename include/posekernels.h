@@ -210,6 +210,27 @@ int pk_ln_mlp_bwd_dx(const void* dy, const void* x, const float* gamma, const fl
 int pk_ln_mlp_bwd_dw(const void* dy, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
                      const void* w2_t, const float* row_scale, float* slabs, int M, int C, int rows_per_sample, float eps,
                      void* stream);
+/* Fused attention half of the HRFormer block (hrformer.py:262-286 with WindowAttention :174-200, window_partition/reverse :67-114),
+ * C = 32 / 64, head_dim 32, window 7:   y = x + row_scale[b] * proj( attention( qkv( LayerNorm(x) ) ) )     x, y: [M][C] bf16 pixel rows.
+ * rowmap[windows*49]: pixel row of every window token, -1 for the reference's zero-pad tokens (LayerNorm output forced to 0, i.e.
+ * q = b_q, k = b_k, v = b_v; attended without a mask, output dropped).  o_save ([windows*49][C] bf16) and lse ([windows][heads][49])
+ * may be NULL (inference); training saves them for pk_attn_block_bwd.  row_scale is indexed by window / windows_per_sample.     */
+int pk_attn_block_supported(int C, int heads);
+int pk_attn_block_fwd(const void* x, const int32_t* rowmap, const float* gamma, const float* beta, const float* rel_table,
+                      const void* wqkv, const float* bqkv, const void* wproj, const float* bproj, const float* row_scale,
+                      void* y, void* o_save, float* lse, int n_windows, int windows_per_sample, int heads, int C, float eps,
+                      void* stream);
+/* Backward of the fused attention half: dx = dy + dLayerNorm(dqkv W_qkv) written to the pixel rows (pad tokens dropped); emits
+ * dqkv [windows*49][3C] bf16 and the LayerNorm output u in window order [windows*49][C] (zero rows at the pad tokens) for the
+ * weight-gradient GEMMs (pk_wgrad_bf16: dW_qkv = dqkv^T u, dW_proj = (s dy)^T o), ln_partial[pk_attn_block_blocks][2][C]
+ * (dgamma | dbeta sums) and rpb_partial[pk_attn_block_blocks*4][heads][169] (rel-pos-bias gradient per wave).  wqkv_t = [C][3C],
+ * wproj_t = [C][C] data-gradient copies; o_saved / lse from pk_attn_block_fwd.                                                */
+int pk_attn_block_blocks(int n_windows);
+int pk_attn_block_bwd(const void* dy, const void* x, const int32_t* rowmap, const float* gamma, const float* beta,
+                      const float* rel_table, const void* wqkv, const float* bqkv, const void* wqkv_t, const void* wproj_t,
+                      const float* row_scale, const void* o_saved, const float* lse, void* dx, void* dqkv, void* u_out,
+                      float* ln_partial, float* rpb_partial, int n_windows, int windows_per_sample, int heads, int C, float eps,
+                      void* stream);
 int pk_colsum_bf16(const void* g, const int32_t* rowmap, const float* row_scale, int rows_per_sample, float* partial,
                    float* out, int64_t rows, int N, void* stream);
 /* exchange unit sum (hrformer.py:471-489 == hrnet.py:207-225): out = relu?(sum_i bilinear_up_i(x_i)), F.interpolate

@@ -577,6 +577,638 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dw(MlpArgs p) {
     for (int i = tid * 4; i < SLAB; i += 1024) *reinterpret_cast<f32x4*>(dst + i) = *reinterpret_cast<const f32x4*>(slab + i);
 }
 
+// ================================================================================================ attention half: forward
+//   y = x + s * proj( window_attention( qkv( LayerNorm1(x) ) ) )         (hrformer.py:262-286, WindowAttention :174-200)
+// One wave per 7x7 window (all heads, head_dim 32), tokens padded 49 -> 64 for the MFMA tiles.  The reference zero-pads the map
+// to a multiple of 7 AFTER LayerNorm and attends the pad tokens without a mask: their LN output is forced to 0 here (q = b_q,
+// k = b_k, v = b_v), only the tile padding 49..63 is masked.  Everything is chained through accumulators:
+//   * Q^T, K^T tiles D[e][token] = W rows (A) x u (B): packed, they are the B operand (queries) / A operand (keys) of the score
+//     MFMA S^T = K Q^T with the head dimension enumerated in accumulator order on both sides;
+//   * V tiles D[token][e] = u (A) x W_v rows (B): packed over token tiles they are the A operand V^T of O^T = V^T P^T with the
+//     keys in accumulator order -- the order the register-resident probabilities P^T come in (see pk_attn.hip);
+//   * the W_v rows are gathered with the same hid() permutation as in the MLP, so the packed O^T tiles are the B operand of
+//     the projection with the channels in natural order.
+// Training mode also writes the attention output o (window order, [windows*49][C]) and the log-sum-exp for the backward pass.
+struct AttnArgs {
+    const uint16_t* x;        // [M][C] pixel rows
+    const uint16_t* dy;       // backward
+    uint16_t* out;            // forward: y; backward: dx
+    const int32_t* rowmap;    // [windows*49] pixel row of each window token, -1 = zero-pad token
+    const float *gamma, *beta, *table, *bqkv, *bproj, *scale;
+    const uint16_t *wqkv, *wproj;          // forward copies [3C][C], [C][C]
+    const uint16_t *wqkv_t, *wproj_t;      // data-gradient copies [C][3C], [C][C]
+    uint16_t* o_save;         // [windows*49][C] attention output before the projection, or null
+    float* lse;               // [windows][heads][49], or null
+    uint16_t* dqkv;           // backward: [windows*49][3C]
+    uint16_t* u_save;         // backward: LayerNorm output in window order [windows*49][C] (zero rows for the pad tokens)
+    float* part;              // backward slabs
+    int n_windows, windows_per_sample;
+    float eps, softmax_scale;
+    int dbg;                  // experiment knobs (env PK_ATTN_DBG; timing only, wrong results): 1 no LDS adds, 2 no phase 2, 4 no pass 2, 8 no pass 1
+};
+#define AT_N 49
+__device__ __forceinline__ int rel_a7(int t) { return 13 * (t / 7) + t % 7; }   // rel_index(i, j) = rel_a7(i) - rel_a7(j) + 84
+
+template <int C>
+__global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs p) {
+    constexpr int HEADS = C / 32, NK = C / 32, NCT = C / 16;
+    __shared__ __attribute__((aligned(16))) u32x4 sWqkv[HEADS * 6 * NK * 64];   // fragment ((h*3 + part)*2 + et)*NK + k
+    __shared__ __attribute__((aligned(16))) u32x4 sWp[NCT * HEADS * 64];        // fragment nt*HEADS + h: rows 16nt + i, channels 32h + 8g ..
+    __shared__ __attribute__((aligned(16))) float sBqkv[3 * C];
+    __shared__ float sBias[HEADS][176];
+    const int tid = threadIdx.x, lane_ = tid & 63, wave = tid >> 6, g_ = lane_ >> 4;
+    stage_frags(sWqkv, p.wqkv, HEADS * 6 * NK, C,
+                [](int f, int i) {
+                    const int k_ = f % NK, r = f / NK, et = r & 1, part = (r >> 1) % 3, h = r / 6;
+                    (void)k_;
+                    return part * C + 32 * h + (part == 2 ? hid(et, i) : 16 * et + i);
+                },
+                [](int f) { return 32 * (f % NK); });
+    stage_frags(sWp, p.wproj, NCT * HEADS, C, [](int f, int i) { return 16 * (f / HEADS) + i; }, [](int f) { return 32 * (f % HEADS); });
+    for (int i = tid; i < 3 * C; i += 256) sBqkv[i] = p.bqkv[i];
+    for (int i = tid; i < HEADS * 169; i += 256) sBias[i / 169][i % 169] = p.table[(i % 169) * HEADS + i / 169];
+    float gam[NK][8], bet[NK][8];
+#pragma unroll
+    for (int k = 0; k < NK; ++k)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            gam[k][j] = p.gamma[32 * k + 8 * g_ + j];
+            bet[k][j] = p.beta[32 * k + 8 * g_ + j];
+        }
+    f32x4 bpv[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) bpv[ct] = *reinterpret_cast<const f32x4*>(p.bproj + 16 * ct + 4 * g_);
+    int aj[4][4];                       // 84 - A(j) for this lane's 16 keys j = 16cj + 4g + r (-1: tile padding)
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * cj + 4 * g_ + r;
+            aj[cj][r] = j < AT_N ? 84 - rel_a7(j) : -1;
+        }
+    __syncthreads();
+    const auto rx = MAKE_RSRC(p.x);
+    const auto ro = MAKE_RSRC(p.out);
+    const float inv_c = 1.f / (float)C;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int w = blockIdx.x * 4 + wave; w < p.n_windows; w += gridDim.x * 4) {
+        // (opaque lane id: keeps the weight-fragment reads AND the 64 bias-table lookups per head inside the window loop)
+        const int lane = opaque_lane<true>(lane_), i16 = lane & 15, g = lane >> 4;
+        int row[4];
+        u32x4 xr[4][NK];
+        u32x2 xo[4][NCT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = 16 * t + i16;
+            row[t] = n < AT_N ? p.rowmap[w * AT_N + n] : -1;
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned base = row[t] >= 0 ? (unsigned)row[t] * (unsigned)(C * 2) : OOB_OFF;
+#pragma unroll
+            for (int k = 0; k < NK; ++k) xr[t][k] = __builtin_amdgcn_raw_buffer_load_b128(rx, row[t] >= 0 ? base + (32 * k + 8 * g) * 2 : OOB_OFF, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) xo[t][ct] = __builtin_amdgcn_raw_buffer_load_b64(rx, row[t] >= 0 ? base + (16 * ct + 4 * g) * 2 : OOB_OFF, 0, 0);
+        }
+        const float sc = p.scale ? p.scale[w / p.windows_per_sample] : 1.f;
+        bf16x8 uf[4][NK];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            float mean, rstd;
+            ln_row<NK>(xr[t], gam, bet, inv_c, p.eps, uf[t], mean, rstd);
+            if (row[t] < 0) {          // zero-pad token (or tile padding): the reference pads AFTER LayerNorm
+#pragma unroll
+                for (int k = 0; k < NK; ++k) uf[t][k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        f32x4 accY[4][NCT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) accY[t][ct] = zero;
+#pragma unroll 1
+        for (int h = 0; h < HEADS; ++h) {
+            bf16x8 qf[4], kf[4], vt[2][2];
+            {
+                f32x4 va[4][2];
+#pragma unroll
+                for (int ce = 0; ce < 2; ++ce) {
+                    const float bv = sBqkv[2 * C + 32 * h + hid(ce, i16)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) va[t][ce] = (f32x4){bv, bv, bv, bv};
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const bf16x8 wv = LDS_FRAG(sWqkv, ((h * 3 + 2) * 2 + ce) * NK + k, lane);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) va[t][ce] = MFMA(uf[t][k], wv, va[t][ce]);       // D[token][e]
+                    }
+                }
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int ce = 0; ce < 2; ++ce) vt[s][ce] = pack2(va[2 * s][ce], va[2 * s + 1][ce]);
+            }
+            {
+                f32x4 qa[4][2], ka[4][2];
+#pragma unroll
+                for (int et = 0; et < 2; ++et) {
+                    const f32x4 bq = *reinterpret_cast<const f32x4*>(&sBqkv[32 * h + 16 * et + 4 * g]);
+                    const f32x4 bk = *reinterpret_cast<const f32x4*>(&sBqkv[C + 32 * h + 16 * et + 4 * g]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        qa[t][et] = bq;
+                        ka[t][et] = bk;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const bf16x8 wq = LDS_FRAG(sWqkv, ((h * 3 + 0) * 2 + et) * NK + k, lane);
+                        const bf16x8 wk = LDS_FRAG(sWqkv, ((h * 3 + 1) * 2 + et) * NK + k, lane);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            qa[t][et] = MFMA(wq, uf[t][k], qa[t][et]);                            // D[e][token]
+                            ka[t][et] = MFMA(wk, uf[t][k], ka[t][et]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    qf[t] = pack2(qa[t][0], qa[t][1]);
+                    kf[t] = pack2(ka[t][0], ka[t][1]);
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                const int i = 16 * ci + i16;
+                const int ai = rel_a7(i < AT_N ? i : 0);
+                f32x4 st[4];
+#pragma unroll
+                for (int cj = 0; cj < 4; ++cj) st[cj] = MFMA(kf[cj], qf[ci], zero);
+                float mx = -INFINITY;
+#pragma unroll
+                for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float bv = sBias[h][ai + (aj[cj][r] >= 0 ? aj[cj][r] : 0)];
+                        st[cj][r] = aj[cj][r] >= 0 ? st[cj][r] * p.softmax_scale + bv : -INFINITY;
+                        mx = fmaxf(mx, st[cj][r]);
+                    }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                float sum = 0.f;
+#pragma unroll
+                for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[cj][r] = __expf(st[cj][r] - mx);
+                        sum += st[cj][r];
+                    }
+                sum += __shfl_xor(sum, 16, 64);
+                sum += __shfl_xor(sum, 32, 64);
+                const float inv = 1.f / sum;
+                if (g == 0 && i < AT_N && p.lse) p.lse[((size_t)w * HEADS + h) * AT_N + i] = mx + __logf(sum);
+                const bf16x8 p0 = pack2(st[0] * inv, st[1] * inv), p1 = pack2(st[2] * inv, st[3] * inv);
+                f32x4 o[2];
+#pragma unroll
+                for (int ce = 0; ce < 2; ++ce) {
+                    o[ce] = MFMA(vt[0][ce], p0, zero);
+                    o[ce] = MFMA(vt[1][ce], p1, o[ce]);         // rows 4g + r of tile ce  <->  channel 32h + 8g + 4ce + r
+                    if (p.o_save && i < AT_N)
+                        *reinterpret_cast<u32x2*>(p.o_save + ((size_t)w * AT_N + i) * C + 32 * h + 8 * g + 4 * ce) = pack4(o[ce]);
+                }
+                const bf16x8 of = pack2(o[0], o[1]);
+#pragma unroll
+                for (int nt = 0; nt < NCT; ++nt) accY[ci][nt] = MFMA(LDS_FRAG(sWp, nt * HEADS + h, lane), of, accY[ci][nt]);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f32x4 v = (accY[t][ct] + bpv[ct]) * sc + unpack4(xo[t][ct]);
+                __builtin_amdgcn_raw_buffer_store_b64(pack4(v), ro, row[t] >= 0 ? (unsigned)row[t] * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF, 0, 0);
+            }
+    }
+}
+
+// ================================================================================================ attention half: backward
+// One wave per window again; LayerNorm, q, k, v are recomputed from x, the projection's data gradient dO = (s dy) W_p is
+// computed in-kernel, the attention core follows pk_attn.hip's two-pass formulation (P recomputed from the saved log-sum-exp in
+// both layouts, delta_i = sum_e dO O from the saved output), and the qkv data gradient + LayerNorm backward + residual gradient
+// are applied before anything leaves the registers:
+//     dx = dy + dLN1( [dq | dk | dv] W_qkv ),   written to the pixel rows of the window's real tokens.
+// Every MFMA operand is produced by an MFMA in the layout its consumer needs ("token form": lane = token, slots = head channels;
+// "e form": lane = head channel, slots = tokens), so no tile is transposed through LDS.  The e-form weight rows are gathered with
+// hid() so that the packed dq / dk / dv tiles are B operands in natural channel order for the qkv data-gradient MFMA.
+// Emitted for the weight-gradient GEMMs (pk_wgrad_bf16): dqkv [windows*49][3C] and the LayerNorm output u in window order
+// (zero rows for the pad tokens).  part_ln[block][2][C]: dgamma | dbeta sums; part_rpb[(block*4 + wave)][heads][169]: rel-pos-bias
+// gradient folded per wave (fixed order, deterministic).
+template <int C>
+__global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restrict__ part_ln, float* __restrict__ part_rpb) {
+    constexpr int HEADS = C / 32, NK = C / 32, NCT = C / 16, NKQ = 3 * C / 32;
+    constexpr int F_A = 6 * NK, F_B = 4 * NK;                      // per head: token-form q/k/v rows, e-form q/k rows
+    __shared__ __attribute__((aligned(16))) u32x4 sWa[HEADS * F_A * 64];       // ((h*3 + part)*2 + et)*NK + k : rows part*C + 32h + 16et + i
+    __shared__ __attribute__((aligned(16))) u32x4 sWb[HEADS * F_B * 64];       // ((h*2 + part)*2 + ce)*NK + k : rows part*C + 32h + hid(ce, i)
+    __shared__ __attribute__((aligned(16))) u32x4 sPa[HEADS * 2 * NK * 64];    // (h*2 + et)*NK + k : W_p^T rows 32h + 16et + i
+    __shared__ __attribute__((aligned(16))) u32x4 sPb[HEADS * 2 * NK * 64];    // (h*2 + ce)*NK + k : W_p^T rows 32h + hid(ce, i)
+    __shared__ __attribute__((aligned(16))) u32x4 sWt[NCT * NKQ * 64];         // ct*NKQ + kq : W_qkv^T rows 16ct + i, columns 32kq + 8g ..
+    __shared__ __attribute__((aligned(16))) float sBqkv[3 * C];
+    __shared__ __attribute__((aligned(16))) float sGam[C], sBet[C];
+    __shared__ __attribute__((aligned(16))) int sA[64];                        // A(t) = 13 (t / 7) + t % 7 of token t, -1 for the tile padding
+    __shared__ float sBias[HEADS][176];
+    __shared__ __attribute__((aligned(16))) float sLse[4][64], sDelta[4][64];
+    __shared__ float sTab[4][HEADS][192];                                      // rel-pos-bias gradient of this wave: entry e owned by lane e % 64
+    __shared__ float sFold[4][AT_N * AT_N];                                    // dS of the current (window, head), folded onto sTab once per window
+    __shared__ float sRed[4][2][C];
+    const int tid = threadIdx.x, lane_ = tid & 63, wave = tid >> 6;
+    stage_frags(sWa, p.wqkv, HEADS * F_A, C,
+                [](int f, int i) { const int r = f / NK, et = r & 1, part = (r >> 1) % 3, h = r / 6; return part * C + 32 * h + 16 * et + i; },
+                [](int f) { return 32 * (f % NK); });
+    stage_frags(sWb, p.wqkv, HEADS * F_B, C,
+                [](int f, int i) { const int r = f / NK, ce = r & 1, part = (r >> 1) & 1, h = r / 4; return part * C + 32 * h + hid(ce, i); },
+                [](int f) { return 32 * (f % NK); });
+    stage_frags(sPa, p.wproj_t, HEADS * 2 * NK, C, [](int f, int i) { const int r = f / NK; return 32 * (r >> 1) + 16 * (r & 1) + i; },
+                [](int f) { return 32 * (f % NK); });
+    stage_frags(sPb, p.wproj_t, HEADS * 2 * NK, C, [](int f, int i) { const int r = f / NK; return 32 * (r >> 1) + hid(r & 1, i); },
+                [](int f) { return 32 * (f % NK); });
+    stage_frags(sWt, p.wqkv_t, NCT * NKQ, 3 * C, [](int f, int i) { return 16 * (f / NKQ) + i; }, [](int f) { return 32 * (f % NKQ); });
+    for (int i = tid; i < 3 * C; i += 256) sBqkv[i] = p.bqkv[i];
+    for (int i = tid; i < C; i += 256) {
+        sGam[i] = p.gamma[i];
+        sBet[i] = p.beta[i];
+    }
+    if (tid < 64) sA[tid] = tid < AT_N ? rel_a7(tid) : -1;
+    for (int i = tid; i < HEADS * 169; i += 256) sBias[i / 169][i % 169] = p.table[(i % 169) * HEADS + i / 169];
+    for (int i = tid; i < 4 * HEADS * 192; i += 256) (&sTab[0][0][0])[i] = 0.f;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 dgam[NCT], dbet[NCT];
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct) dgam[ct] = dbet[ct] = zero;
+    __syncthreads();
+    const auto rx = MAKE_RSRC(p.x);
+    const auto rg = MAKE_RSRC(p.dy);
+    const auto ro = MAKE_RSRC(p.out);
+    const auto rs = MAKE_RSRC(p.o_save);
+    const auto rq = MAKE_RSRC(p.dqkv);
+    const float inv_c = 1.f / (float)C, scale = p.softmax_scale;
+    for (int w = blockIdx.x * 4 + wave; w < p.n_windows; w += gridDim.x * 4) {
+        const int lane = opaque_lane<true>(lane_), i16 = lane & 15, g = lane >> 4;
+        int row[4];
+        float mean[4], rstd[4];
+        {   // ================= phase 1: the attention core; writes dqkv (and u) rows of this window
+            u32x4 xr[4][NK], dyr[4][NK];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int n = 16 * t + i16;
+                row[t] = n < AT_N ? p.rowmap[w * AT_N + n] : -1;
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    const unsigned off = row[t] >= 0 ? (unsigned)row[t] * (unsigned)(C * 2) + (32 * k + 8 * g) * 2 : OOB_OFF;
+                    xr[t][k] = __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0);
+                    dyr[t][k] = __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0);
+                }
+            const float sc = p.scale ? p.scale[w / p.windows_per_sample] : 1.f;
+            bf16x8 uf[4][NK], gf[4][NK];
+            {
+                float gam[NK][8], bet[NK][8];
+#pragma unroll
+                for (int k = 0; k < NK; ++k) {
+                    *reinterpret_cast<f32x4*>(&gam[k][0]) = *reinterpret_cast<const f32x4*>(&sGam[32 * k + 8 * g]);
+                    *reinterpret_cast<f32x4*>(&gam[k][4]) = *reinterpret_cast<const f32x4*>(&sGam[32 * k + 8 * g + 4]);
+                    *reinterpret_cast<f32x4*>(&bet[k][0]) = *reinterpret_cast<const f32x4*>(&sBet[32 * k + 8 * g]);
+                    *reinterpret_cast<f32x4*>(&bet[k][4]) = *reinterpret_cast<const f32x4*>(&sBet[32 * k + 8 * g + 4]);
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    ln_row<NK>(xr[t], gam, bet, inv_c, p.eps, uf[t], mean[t], rstd[t]);
+                    scale_rows<NK>(dyr[t], sc, gf[t]);
+                    if (row[t] < 0) {
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) uf[t][k] = (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+                    }
+                    if (16 * t + i16 < AT_N) {
+#pragma unroll
+                        for (int k = 0; k < NK; ++k)
+                            *reinterpret_cast<bf16x8*>(p.u_save + ((size_t)w * AT_N + 16 * t + i16) * C + 32 * k + 8 * g) = uf[t][k];
+                    }
+                }
+            }
+            uint16_t* dq_base = p.dqkv + (size_t)w * AT_N * 3 * C;
+#pragma unroll 1
+            for (int h = 0; h < HEADS; ++h) {
+                // ---- token-form operands: lane = token, slots = head channel e = 16 (jj >> 2) + 4g + (jj & 3)
+                bf16x8 qf[4], kf[4], vf[4], dof[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    f32x4 a[4][2];      // [q, k, v, dO][et]
+#pragma unroll
+                    for (int et = 0; et < 2; ++et) {
+#pragma unroll
+                        for (int part = 0; part < 3; ++part) a[part][et] = *reinterpret_cast<const f32x4*>(&sBqkv[part * C + 32 * h + 16 * et + 4 * g]);
+                        a[3][et] = zero;
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) {
+#pragma unroll
+                            for (int part = 0; part < 3; ++part)
+                                a[part][et] = MFMA(LDS_FRAG(sWa, ((h * 3 + part) * 2 + et) * NK + k, lane), uf[t][k], a[part][et]);
+                            a[3][et] = MFMA(LDS_FRAG(sPa, (h * 2 + et) * NK + k, lane), gf[t][k], a[3][et]);
+                        }
+                    }
+                    qf[t] = pack2(a[0][0], a[0][1]);
+                    kf[t] = pack2(a[1][0], a[1][1]);
+                    vf[t] = pack2(a[2][0], a[2][1]);
+                    dof[t] = pack2(a[3][0], a[3][1]);
+                    // delta_i = sum_e dO[i][e] O[i][e]: this lane's 8 channels of token i = 16t + i16, then the 4 lanes of the token
+                    const int i = 16 * t + i16;
+                    const unsigned ob = i < AT_N ? (unsigned)((w * AT_N + i) * C + 32 * h + 4 * g) * 2u : OOB_OFF;
+                    const f32x4 o0 = unpack4(__builtin_amdgcn_raw_buffer_load_b64(rs, ob, 0, 0));
+                    const f32x4 o1 = unpack4(__builtin_amdgcn_raw_buffer_load_b64(rs, i < AT_N ? ob + 32 : OOB_OFF, 0, 0));
+                    float de = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) de += a[3][0][r] * o0[r] + a[3][1][r] * o1[r];
+                    de += __shfl_xor(de, 16, 64);
+                    de += __shfl_xor(de, 32, 64);
+                    const float l = i < AT_N ? p.lse[((size_t)w * HEADS + h) * AT_N + i] : 0.f;
+                    if (g == 0) {
+                        sLse[wave][i] = l;
+                        sDelta[wave][i] = de;
+                    }
+                }
+                // ---- e-form operands (lane = head channel hid(ce, i16), slots = the 32 tokens of K-step s in accumulator order): K now,
+                //      Q and dO after pass 1 (fewer live registers)
+                bf16x8 Kt[2][2];
+#pragma unroll
+                for (int ce = 0; ce < 2; ++ce) {
+                    f32x4 a[4];
+                    const float bk = sBqkv[C + 32 * h + hid(ce, i16)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) a[t] = (f32x4){bk, bk, bk, bk};
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const bf16x8 wk = LDS_FRAG(sWb, ((h * 2 + 1) * 2 + ce) * NK + k, lane);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) a[t] = MFMA(uf[t][k], wk, a[t]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) Kt[s][ce] = pack2(a[2 * s], a[2 * s + 1]);
+                }
+                LDS_FENCE();                // sLse / sDelta of this wave are visible to its own reads below
+                // ---- pass 1: transposed scores, lane = query i:  dS^T, bias gradient, dQ^T = scale * K^T dS^T
+#pragma unroll
+                for (int ci = 0; ci < ((p.dbg & 8) ? 0 : 4); ++ci) {
+                    const int i = 16 * ci + i16;
+                    const bool iok = i < AT_N;
+                    const int ai = rel_a7(iok ? i : 0) + 84;
+                    const float li = sLse[wave][i], di = sDelta[wave][i];
+                    f32x4 dq[2] = {zero, zero};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        f32x4 ds[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int cj = 2 * s + u;
+                            const f32x4 scr = MFMA(kf[cj], qf[ci], zero), dp = MFMA(vf[cj], dof[ci], zero);
+                            const int4 aj = *reinterpret_cast<const int4*>(&sA[16 * cj + 4 * g]);
+                            const int ajr[4] = {aj.x, aj.y, aj.z, aj.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int e = ai - (ajr[r] >= 0 ? ajr[r] : 0);
+                                const float ev = __expf(scr[r] * scale + sBias[h][e] - li);
+                                const float pv = (iok && ajr[r] >= 0) ? ev : 0.f;
+                                ds[u][r] = pv * (dp[r] - di);
+                                // d(bias)[i][j] of this window -> wave-private tile, folded onto the 169 table entries after the pass.
+                                // (LDS float atomics straight into the table were measured: ~200 cycles per ds_add_f32 wave-instruction,
+                                // 95 us of a 159 us kernel; 64 accumulator registers per head instead cost a wave of occupancy.)
+                                if (iok && ajr[r] >= 0 && !(p.dbg & 1)) sFold[wave][i * AT_N + 16 * cj + 4 * g + r] = ds[u][r];
+                            }
+                        }
+                        const bf16x8 df = pack2(ds[0], ds[1]);
+#pragma unroll
+                        for (int ce = 0; ce < 2; ++ce) dq[ce] = MFMA(Kt[s][ce], df, dq[ce]);
+                    }
+#pragma unroll
+                    for (int ce = 0; ce < 2; ++ce)      // rows 4g + r of tile ce  <->  head channel 8g + 4ce + r
+                        if (iok) *reinterpret_cast<u32x2*>(dq_base + (size_t)i * 3 * C + 32 * h + 8 * g + 4 * ce) = pack4(dq[ce] * scale);
+                }
+                if (!(p.dbg & 1)) {        // fold: table entry e = (dy + 6) * 13 + dx + 6 sums dS[i][j] over the pairs with i - j = (dy, dx)
+                    LDS_FENCE();
+                    for (int e = lane; e < 169; e += 64) {
+                        const int dy_ = e / 13 - 6, dx_ = e % 13 - 6;
+                        float acc = 0.f;
+                        for (int yj = max(0, -dy_); yj < min(7, 7 - dy_); ++yj)
+                            for (int xj = max(0, -dx_); xj < min(7, 7 - dx_); ++xj)
+                                acc += sFold[wave][((yj + dy_) * 7 + xj + dx_) * AT_N + yj * 7 + xj];
+                        sTab[wave][h][e] += acc;
+                    }
+                    LDS_FENCE();
+                }
+                bf16x8 Qt[2][2], dOt[2][2];
+#pragma unroll
+                for (int ce = 0; ce < 2; ++ce) {
+                    f32x4 a[2][4];
+                    const float bq = sBqkv[32 * h + hid(ce, i16)];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        a[0][t] = (f32x4){bq, bq, bq, bq};
+                        a[1][t] = zero;
+                    }
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const bf16x8 wq = LDS_FRAG(sWb, ((h * 2 + 0) * 2 + ce) * NK + k, lane), wp = LDS_FRAG(sPb, (h * 2 + ce) * NK + k, lane);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            a[0][t] = MFMA(uf[t][k], wq, a[0][t]);
+                            a[1][t] = MFMA(gf[t][k], wp, a[1][t]);
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        Qt[s][ce] = pack2(a[0][2 * s], a[0][2 * s + 1]);
+                        dOt[s][ce] = pack2(a[1][2 * s], a[1][2 * s + 1]);
+                    }
+                }
+                // ---- pass 2: plain scores, lane = key j:  dV^T = dO^T P,  dK^T = scale * Q^T dS
+#pragma unroll
+                for (int cj = 0; cj < ((p.dbg & 4) ? 0 : 4); ++cj) {
+                    const int j = 16 * cj + i16;
+                    const bool jok = j < AT_N;
+                    const int ajn = 84 - rel_a7(jok ? j : 0);
+                    f32x4 dv[2] = {zero, zero}, dk[2] = {zero, zero};
+#pragma unroll
+                    for (int s = 0; s < 2; ++s) {
+                        f32x4 pp[2], ds[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int ci = 2 * s + u;
+                            const f32x4 scr = MFMA(qf[ci], kf[cj], zero), dp = MFMA(dof[ci], vf[cj], zero);
+                            const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sLse[wave][16 * ci + 4 * g]);
+                            const f32x4 de4 = *reinterpret_cast<const f32x4*>(&sDelta[wave][16 * ci + 4 * g]);
+                            const int4 aq = *reinterpret_cast<const int4*>(&sA[16 * ci + 4 * g]);
+                            const int aqr[4] = {aq.x, aq.y, aq.z, aq.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const float ev = __expf(scr[r] * scale + sBias[h][(aqr[r] >= 0 ? aqr[r] : 0) + ajn] - l4[r]);
+                                const float pv = (jok && aqr[r] >= 0) ? ev : 0.f;
+                                pp[u][r] = pv;
+                                ds[u][r] = pv * (dp[r] - de4[r]);
+                            }
+                        }
+                        const bf16x8 pf = pack2(pp[0], pp[1]), df = pack2(ds[0], ds[1]);
+#pragma unroll
+                        for (int ce = 0; ce < 2; ++ce) {
+                            dv[ce] = MFMA(dOt[s][ce], pf, dv[ce]);
+                            dk[ce] = MFMA(Qt[s][ce], df, dk[ce]);
+                        }
+                    }
+#pragma unroll
+                    for (int ce = 0; ce < 2; ++ce)
+                        if (jok) {
+                            *reinterpret_cast<u32x2*>(dq_base + (size_t)j * 3 * C + C + 32 * h + 8 * g + 4 * ce) = pack4(dk[ce] * scale);
+                            *reinterpret_cast<u32x2*>(dq_base + (size_t)j * 3 * C + 2 * C + 32 * h + 8 * g + 4 * ce) = pack4(dv[ce]);
+                        }
+                }
+                LDS_FENCE();                // the reads of sLse / sDelta complete before the next head rewrites them
+            }
+        }
+        // ================= phase 2: du = dqkv W_qkv from the rows this wave has just written (bf16, exactly what the weight-gradient
+        // GEMM will read), LayerNorm backward + residual gradient in accumulator layout, one token tile at a time
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's dqkv stores have completed before it reads them back
+#pragma unroll
+        for (int t = 0; t < ((p.dbg & 2) ? 0 : 4); ++t) {
+            const int n = 16 * t + i16;
+            const int rw = row[t];
+            const float mu = mean[t], rsd = rstd[t];
+            const bool valid = rw >= 0;
+            const unsigned qb = n < AT_N ? (unsigned)((w * AT_N + n) * 3 * C + 8 * g) * 2u : OOB_OFF;
+            f32x4 du[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) du[ct] = zero;
+#pragma unroll
+            for (int kq = 0; kq < NKQ; ++kq) {
+                const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, n < AT_N ? qb + 64 * kq : OOB_OFF, 0, 0));
+#pragma unroll
+                for (int ct = 0; ct < NCT; ++ct) du[ct] = MFMA(LDS_FRAG(sWt, ct * NKQ + kq, lane), b, du[ct]);
+            }
+            u32x2 xo[NCT], dyo[NCT];
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const unsigned off = valid ? (unsigned)rw * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF;
+                xo[ct] = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
+                dyo[ct] = __builtin_amdgcn_raw_buffer_load_b64(rg, off, 0, 0);
+            }
+            f32x4 xh[NCT], gamA[NCT];
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                gamA[ct] = *reinterpret_cast<const f32x4*>(&sGam[16 * ct + 4 * g]);
+                xh[ct] = (unpack4(xo[ct]) - mu) * rsd;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float gh = du[ct][r] * gamA[ct][r];
+                    s1 += gh;
+                    s2 += gh * xh[ct][r];
+                }
+                if (valid) {            // pad tokens are not LayerNorm outputs: their gradient is dropped (hrformer.py:103-114)
+                    dgam[ct] += du[ct] * xh[ct];
+                    dbet[ct] += du[ct];
+                }
+            }
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const float m1 = s1 * inv_c, m2 = s2 * inv_c;
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const f32x4 o = (du[ct] * gamA[ct] - m1 - xh[ct] * m2) * rsd + unpack4(dyo[ct]);
+                __builtin_amdgcn_raw_buffer_store_b64(pack4(o), ro, valid ? (unsigned)rw * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF, 0, 0);
+            }
+        }
+    }
+    // ---- dgamma / dbeta: over the 16 tokens of a lane group, then over the 4 waves
+    const int i16 = lane_ & 15, g = lane_ >> 4;
+#pragma unroll
+    for (int ct = 0; ct < NCT; ++ct)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float a = dgam[ct][r], b = dbet[ct][r];
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) {
+                a += __shfl_xor(a, o, 64);
+                b += __shfl_xor(b, o, 64);
+            }
+            if (i16 == 0) {
+                sRed[wave][0][16 * ct + 4 * g + r] = a;
+                sRed[wave][1][16 * ct + 4 * g + r] = b;
+            }
+        }
+    __syncthreads();
+    // ---- rel-pos-bias gradient of each wave: [block*4 + wave][head][169]
+    for (int i = tid; i < 4 * HEADS * 169; i += 256) {
+        const int wv = i / (HEADS * 169), r = i % (HEADS * 169);
+        part_rpb[((size_t)blockIdx.x * 4 + wv) * HEADS * 169 + r] = sTab[wv][r / 169][r % 169];
+    }
+    if (tid < 2 * C) {
+        const int which = tid / C, c = tid - which * C;
+        part_ln[(size_t)blockIdx.x * 2 * C + tid] = ((sRed[0][which][c] + sRed[1][which][c]) + sRed[2][which][c]) + sRed[3][which][c];
+    }
+}
+
+static inline int attn_blocks(int n_windows) {
+    static const int cap = getenv("PK_ATTN_WGS") ? atoi(getenv("PK_ATTN_WGS")) : 1024;
+    const int need = (n_windows + 3) / 4;
+    return need < cap ? (need < 1 ? 1 : need) : cap;
+}
+extern "C" int pk_attn_block_blocks(int n_windows) { return attn_blocks(n_windows); }
+extern "C" int pk_attn_block_bwd(const void* dy, const void* x, const int32_t* rowmap, const float* gamma, const float* beta,
+                                 const float* rel_table, const void* wqkv, const float* bqkv, const void* wqkv_t, const void* wproj_t,
+                                 const float* row_scale, const void* o_saved, const float* lse, void* dx, void* dqkv, void* u_out,
+                                 float* ln_partial, float* rpb_partial, int n_windows, int windows_per_sample, int heads, int C, float eps,
+                                 void* stream) {
+    PK_SUPPORTED((C == 32 || C == 64) && heads * 32 == C, "pk_attn_block_bwd: C=%d heads=%d (built for C = 32 / 64 with head_dim 32)", C, heads);
+    PK_REQUIRE(dy && x && rowmap && gamma && beta && rel_table && wqkv && bqkv && wqkv_t && wproj_t && o_saved && lse && dx && dqkv && u_out &&
+               ln_partial && rpb_partial && n_windows > 0, "pk_attn_block_bwd: null pointer");
+    PK_REQUIRE(!row_scale || windows_per_sample > 0, "pk_attn_block_bwd: row_scale needs windows_per_sample");
+    PK_REQUIRE(((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)wqkv) | ((uintptr_t)wqkv_t) | ((uintptr_t)wproj_t) |
+                 ((uintptr_t)o_saved) | ((uintptr_t)dqkv) | ((uintptr_t)u_out) | ((uintptr_t)gamma)) & 15) == 0, "pk_attn_block_bwd: 16-byte alignment");
+    PK_REQUIRE((int64_t)n_windows * AT_N * 3 * C < 0x3fffffffLL, "pk_attn_block_bwd: too large for 32-bit offsets");
+    AttnArgs a{};
+    a.x = (const uint16_t*)x; a.dy = (const uint16_t*)dy; a.out = (uint16_t*)dx; a.rowmap = rowmap; a.gamma = gamma; a.beta = beta;
+    a.table = rel_table; a.bqkv = bqkv; a.scale = row_scale; a.wqkv = (const uint16_t*)wqkv; a.wqkv_t = (const uint16_t*)wqkv_t;
+    a.wproj_t = (const uint16_t*)wproj_t; a.o_save = (uint16_t*)const_cast<void*>(o_saved); a.lse = const_cast<float*>(lse);
+    a.dqkv = (uint16_t*)dqkv; a.u_save = (uint16_t*)u_out; a.n_windows = n_windows;
+    a.windows_per_sample = windows_per_sample > 0 ? windows_per_sample : 1; a.eps = eps; a.softmax_scale = 1.f / sqrtf(32.f);
+    static const int dbg = getenv("PK_ATTN_DBG") ? atoi(getenv("PK_ATTN_DBG")) : 0;
+    a.dbg = dbg;
+    const dim3 grid(attn_blocks(n_windows)), block(256);
+    if (C == 32) hipLaunchKernelGGL(k_attn_bwd<32>, grid, block, 0, (hipStream_t)stream, a, ln_partial, rpb_partial);
+    else hipLaunchKernelGGL(k_attn_bwd<64>, grid, block, 0, (hipStream_t)stream, a, ln_partial, rpb_partial);
+    return pk_launch_status("pk_attn_block_bwd");
+}
+extern "C" int pk_attn_block_supported(int C, int heads) { return (C == 32 || C == 64) && heads * 32 == C; }
+extern "C" int pk_attn_block_fwd(const void* x, const int32_t* rowmap, const float* gamma, const float* beta, const float* rel_table,
+                                 const void* wqkv, const float* bqkv, const void* wproj, const float* bproj, const float* row_scale,
+                                 void* y, void* o_save, float* lse, int n_windows, int windows_per_sample, int heads, int C, float eps,
+                                 void* stream) {
+    PK_SUPPORTED(pk_attn_block_supported(C, heads), "pk_attn_block_fwd: C=%d heads=%d (built for C = 32 / 64 with head_dim 32)", C, heads);
+    PK_REQUIRE(x && rowmap && gamma && beta && rel_table && wqkv && bqkv && wproj && bproj && y && n_windows > 0, "pk_attn_block_fwd: null pointer");
+    PK_REQUIRE(!row_scale || windows_per_sample > 0, "pk_attn_block_fwd: row_scale needs windows_per_sample");
+    PK_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)wqkv) | ((uintptr_t)wproj) | ((uintptr_t)o_save) | ((uintptr_t)bproj)) & 15) == 0,
+               "pk_attn_block_fwd: 16-byte alignment");
+    PK_REQUIRE((int64_t)n_windows * AT_N * 3 * C < 0x3fffffffLL, "pk_attn_block_fwd: too large for 32-bit offsets");
+    AttnArgs a{};
+    a.x = (const uint16_t*)x; a.out = (uint16_t*)y; a.rowmap = rowmap; a.gamma = gamma; a.beta = beta; a.table = rel_table; a.bqkv = bqkv;
+    a.bproj = bproj; a.scale = row_scale; a.wqkv = (const uint16_t*)wqkv; a.wproj = (const uint16_t*)wproj; a.o_save = (uint16_t*)o_save;
+    a.lse = lse; a.n_windows = n_windows; a.windows_per_sample = windows_per_sample > 0 ? windows_per_sample : 1; a.eps = eps;
+    a.softmax_scale = 1.f / sqrtf(32.f);
+    const dim3 grid(attn_blocks(n_windows)), block(256);
+    if (C == 32) hipLaunchKernelGGL(k_attn_fwd<32>, grid, block, 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(k_attn_fwd<64>, grid, block, 0, (hipStream_t)stream, a);
+    return pk_launch_status("pk_attn_block_fwd");
+}
+
 // ================================================================================================ C-ABI
 static inline int mlp_hidden_slice(int C) {          // hidden units per blockIdx.y slice of the weight-gradient kernel
     static const int env = getenv("PK_MLP_HS") ? atoi(getenv("PK_MLP_HS")) : 0;

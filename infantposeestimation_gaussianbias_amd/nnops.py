@@ -606,9 +606,14 @@ class _MlpHalf(torch.autograd.Function):
                 None if s_b2 else db2, None, None)
 
 
-def fused_mlp_enabled(C, c_real=0):
+def _fused_widths(var, default):
     import os
-    return c_real in (0, C) and os.environ.get("POSE_FUSED_MLP", "1") != "0" and bool(_lib.lib.pk_ln_mlp_supported(C))
+    return tuple(int(v) for v in os.environ.get(var, default).split(",") if v.strip())
+
+
+def fused_mlp_enabled(C, c_real=0):
+    """POSE_FUSED_MLP = comma-separated channel counts that take the fused MLP half (default: all the kernels are built for)."""
+    return c_real in (0, C) and C in _fused_widths("POSE_FUSED_MLP", "32,64") and bool(_lib.lib.pk_ln_mlp_supported(C))
 
 
 class _MlpHalfFused(torch.autograd.Function):
@@ -672,11 +677,103 @@ class _MlpHalfFused(torch.autograd.Function):
                 None if s_b2 else dbb2, None)
 
 
+def fused_attn_enabled(C, heads, c_real=0, attn_scale=0.0, train=True):
+    """POSE_FUSED_ATTN (training) / POSE_FUSED_ATTN_EVAL (forward only) = channel counts that take the fused attention half."""
+    ok = c_real in (0, C) and not attn_scale and bool(_lib.lib.pk_attn_block_supported(C, heads))
+    # Measured in the captured training step (B = 64): the fused backward pays at C = 32 (3 076 img/s vs 3 003 with C = 64 fused as
+    # well: its 2-head backward holds one wave per SIMD and 133 KB of LDS); forward-only use takes both widths.
+    return ok and C in _fused_widths("POSE_FUSED_ATTN" if train else "POSE_FUSED_ATTN_EVAL", "32" if train else "32,64")
+
+
+def attn_half_fused_forward(x, g1, b1, table, wqkv, bqkv, wproj, bproj, scale1, heads, save=False):
+    """x + s1 * proj(window_attention(qkv(LN1(x)))) in ONE launch (pk_attn_block_fwd; C = 32 / 64, head_dim 32).
+    -> (y, o, lse, rowmap); o / lse only when `save` (training)."""
+    wc = _wc()
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    amap, nwin = window_rowmap(B, H, W, x.device)
+    nw = B * nwin
+    y = _e((B, H, W, C), BF16, x.device)
+    o = _e((nw * WS * WS, C), BF16, x.device) if save else None
+    lse = _e((nw * heads * WS * WS,), F32, x.device) if save else None
+    s1 = None if scale1 is None else scale1.float().contiguous()
+    call("pk_attn_block_fwd", x, amap, g1, b1, table, wc.fwd[id(wqkv)], bqkv, wc.fwd[id(wproj)], bproj, s1, y, o, lse, nw, nwin, heads, C,
+         1e-5, stream_ptr())
+    return y, o, lse, amap
+
+
+class _AttnHalfFused(torch.autograd.Function):
+    """x + s1 * proj(window_attention(qkv(LN1(x)))) as ONE forward launch (pk_attn_block_fwd) and one backward launch for the whole
+    data-gradient chain (pk_attn_block_bwd: proj^T, attention core, qkv^T, LayerNorm backward, residual) that also emits dqkv and the
+    window-ordered LayerNorm output for the two weight-gradient GEMMs.  Saved: x, the attention output o and the log-sum-exp."""
+
+    @staticmethod
+    def forward(ctx, x, g1, b1, table, wqkv, bqkv, wproj, bproj, scale1, heads):
+        ctx.params = (g1, b1, table, wqkv, bqkv, wproj, bproj)
+        wc = _wc()
+        x = x.contiguous()
+        y, o, lse, amap = attn_half_fused_forward(x, g1, b1, table, wqkv, bqkv, wproj, bproj, scale1, heads, save=True)
+        s1 = None if scale1 is None else scale1.float().contiguous()
+        ctx.save_for_backward(x, g1, b1, table, bqkv, s1 if s1 is not None else x.new_empty(0), o, lse, wc.fwd[id(wqkv)], wc.dgrad[id(wqkv)],
+                              wc.dgrad[id(wproj)], amap)
+        ctx.meta = (heads, s1 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, g1, b1, table, bqkv, s1, o, lse, wqkv_f, wqkv_t, wproj_t, amap = ctx.saved_tensors
+        heads, has_s = ctx.meta
+        s1 = s1 if has_s else None
+        B, H, W, C = x.shape
+        dev, M = dy.device, B * H * W
+        nw = amap.numel() // (WS * WS)
+        nwin, Mw = nw // B, nw * WS * WS
+        dy = dy.contiguous()
+        pg1, pb1, ptab, pwqkv, pbqkv, pwproj, pbproj = ctx.params
+        (dg, sg), (db, sb), (dtable, s_t) = _sink(pg1), _sink(pb1), _sink(ptab)
+        nb = _lib.lib.pk_attn_block_blocks(nw)
+        small_sinks = sg and sb and s_t and deferral_enabled()
+        if small_sinks:
+            lnp, rpb = _workspace(dg, "attn_ln", nb * 2 * C), _workspace(dtable, "attn_rpb", nb * 4 * heads * 169)
+        else:
+            lnp, rpb = _e((nb * 2 * C,), F32, dev), _e((nb * 4 * heads * 169,), F32, dev)
+        dx = _e((B, H, W, C), BF16, dev)
+        dqkv, u_w = _e((Mw, 3 * C), BF16, dev), _e((Mw, C), BF16, dev)
+        call("pk_attn_block_bwd", dy, x, amap, g1, b1, table, wqkv_f, bqkv, wqkv_t, wproj_t, s1, o, lse, dx, dqkv, u_w, lnp, rpb, nw, nwin,
+             heads, C, 1e-5, stream_ptr())
+        rows = [(lnp.data_ptr(), dg.data_ptr(), 2 * C, nb, C, 0, 0, 1, 1, 1, 0), (lnp.data_ptr() + 4 * C, db.data_ptr(), 2 * C, nb, C, 0, 0, 1, 1, 1, 0)]
+        for hh in range(heads):              # partial [wave][head][169] -> table[e][head]
+            rows.append((rpb.data_ptr() + 4 * 169 * hh, dtable.data_ptr() + 4 * hh, 169 * heads, nb * 4, 169, 0, 0, 1, 1, heads, 0))
+        if small_sinks:
+            _PENDING.extend(rows)
+        else:
+            _reduce_now(rows, dev)
+        # weight gradients: plain [tokens] x [features] GEMMs over the window-ordered rows
+        dst, s_wq = _sink(pwqkv)
+        dbqkv, s_bq = _sink(pbqkv)
+        dwqkv = _wgrad(u_w, dqkv, 3 * C, C, 1, 1, None, M=Mw, out=dst, dbias=dbqkv, deferred=s_wq and s_bq)
+        dst, s_wp = _sink(pwproj)
+        dbproj, s_bp = _sink(pbproj)
+        dwproj = _wgrad(o, dy.view(M, C), C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw, out=dst, dbias=dbproj,
+                        deferred=s_wp and s_bp)
+        return (dx, None if sg else dg, None if sb else db, None if s_t else dtable, None if s_wq else dwqkv, None if s_bq else dbqkv,
+                None if s_wp else dwproj, None if s_bp else dbproj, None, None)
+
+
 def window_block(x, blk, heads, scale1=None, scale2=None):
     a = blk.attn
     c_real, attn_scale = getattr(blk, "c_real", 0), getattr(blk, "attn_scale", 0.0)      # set on padded twins (models/padded.py)
-    x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
-                        a.proj.weight, a.proj.bias, scale1, heads, c_real, attn_scale)
+    needs_grad = torch.is_grad_enabled() and (x.requires_grad or blk.norm1.weight.requires_grad)
+    if fused_attn_enabled(x.shape[-1], heads, c_real, attn_scale, train=needs_grad):
+        if needs_grad:
+            x = _AttnHalfFused.apply(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+                                     a.proj.weight, a.proj.bias, scale1, heads)
+        else:
+            x = attn_half_fused_forward(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+                                        a.proj.weight, a.proj.bias, scale1, heads)[0]
+    else:
+        x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+                            a.proj.weight, a.proj.bias, scale1, heads, c_real, attn_scale)
     m = blk.mlp
     if fused_mlp_enabled(x.shape[-1], c_real) and m.fc1.weight.shape[0] == 4 * x.shape[-1]:
         return _MlpHalfFused.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2)

@@ -174,13 +174,27 @@ def block_cases(flt):
             a = blk.attn
             aargs = (blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias,
                      s2, heads)
-            fn = lambda: nnops._AttnHalf.apply(x, *aargs)
-            with torch.no_grad():
-                sec = timeit(fn)
-            report(f"{name} attn unfused fwd", sec, None, 4 * M * C)
-            y = fn()
-            sec = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True))
-            report(f"{name} attn unfused bwd (all launches)", sec, None, 6 * M * C)
+            variants = [("attn unfused", lambda: nnops._AttnHalf.apply(x, *aargs))]
+            if nnops.fused_attn_enabled(C, heads):
+                variants.append(("attn FUSED", lambda: nnops._AttnHalfFused.apply(x, *aargs)))
+            for tag, fn in variants:
+                with torch.no_grad():
+                    sec = timeit(fn if "unfused" in tag else (lambda: nnops.attn_half_fused_forward(x, *aargs)))
+                report(f"{name} {tag} fwd", sec, None, 4 * M * C)
+                y = fn()
+                sec = timeit(lambda: torch.autograd.grad(y, x, gy, retain_graph=True))
+                report(f"{name} {tag} bwd (all launches)", sec, None, 6 * M * C)
+            if nnops.fused_attn_enabled(C, heads):
+                amap, nwin = nnops.window_rowmap(B, H, W, x.device)
+                nw = B * nwin
+                y, o, lse, _ = nnops.attn_half_fused_forward(x.detach(), *aargs, save=True)
+                nb = lib.pk_attn_block_blocks(nw)
+                lnp, rpb = torch.empty(nb * 2 * C, device=DEV), torch.empty(nb * 4 * heads * 169, device=DEV)
+                dx, dqkv, u_w = torch.empty_like(x), torch.empty(nw * 49, 3 * C, device=DEV, dtype=BF), torch.empty(nw * 49, C, device=DEV, dtype=BF)
+                sec = timeit(lambda: call("pk_attn_block_bwd", gy, x.detach(), amap, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table,
+                                          wc.fwd[id(a.qkv.weight)], a.qkv.bias, wc.dgrad[id(a.qkv.weight)], wc.dgrad[id(a.proj.weight)], s2, o, lse,
+                                          dx, dqkv, u_w, lnp, rpb, nw, nwin, heads, C, 1e-5, stream_ptr()))
+                report(f"{name} attn FUSED bwd kernel", sec, None, 6 * M * C)
 
 
 if __name__ == "__main__":

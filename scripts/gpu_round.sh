@@ -16,6 +16,6 @@ grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/prof_$tag.log
 python scripts/trace_summary.py $(ls gpurun_out/prof_$tag/*/*kernel_trace.csv | head -1) 3 > gpurun_out/trace_summary_$tag.txt 2>&1
 cp $(ls gpurun_out/prof_$tag/*/*kernel_stats.csv | head -1) gpurun_out/kernel_stats_$tag.csv
 rm -rf gpurun_out/prof_$tag
-head -45 gpurun_out/trace_summary_$tag.txt
+head -34 gpurun_out/trace_summary_$tag.txt; tail -28 gpurun_out/trace_summary_$tag.txt
 timeout -k 10 300 python bench.py --steps 30 --warmup 5 --no-cpu-baseline 2>/dev/null > gpurun_out/bench_$tag.json || exit 1
 grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*\|"launch": "[a-zA-Z, ]*"' gpurun_out/bench_$tag.json

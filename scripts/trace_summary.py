@@ -40,6 +40,30 @@ def main(path, nsteps=3):
     for n, v in sorted(tot.items(), key=lambda kv: -kv[1])[:30]:
         print(f"{v:7.3f} ms {c2[n] // nsteps:5d} x {v / (c2[n] / nsteps) * 1e3:7.1f} us  {n}")
     print(f"sum of kernel time {sum(tot.values()):.2f} ms/step")
+    # Concurrency profile: sweep the timeline; for every instant the number of kernels in flight.  A kernel's "alone" time (it is the
+    # only one running) is on the critical path with nothing hiding it; "shared" time is split evenly between the kernels in flight.
+    ev = []
+    for k, r in enumerate(seg):
+        ev.append((int(r["Start_Timestamp"]), 1, k))
+        ev.append((int(r["End_Timestamp"]), 0, k))
+    ev.sort()
+    live, last = set(), ev[0][0]
+    alone, share, hist = collections.defaultdict(float), collections.defaultdict(float), collections.Counter()
+    for t, kind, k in ev:
+        dt = (t - last) / 1e6 / nsteps
+        if dt > 0:
+            hist[min(len(live), 6)] += dt
+            for j in live:
+                n = seg[j]["Kernel_Name"][:64]
+                share[n] += dt / len(live)
+                if len(live) == 1:
+                    alone[n] += dt
+        last = t
+        (live.add if kind else live.discard)(k)
+    print("time by number of kernels in flight (ms/step): " + ", ".join(f"{k}: {v:.2f}" for k, v in sorted(hist.items())))
+    print("kernel time when nothing else runs (alone) / fair share of wall time, top 25:")
+    for n, v in sorted(share.items(), key=lambda kv: -kv[1])[:25]:
+        print(f"{alone[n]:7.3f} ms alone {v:7.3f} ms share  {n}")
 
 
 if __name__ == "__main__":

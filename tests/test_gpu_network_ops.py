@@ -581,3 +581,96 @@ def test_fused_mlp_half_vs_torch_and_unfused(N, monkeypatch, Cc, B, H, W, scaled
         assert err(gp[k], gpu_[k]) < 2e-2, k
     if s2 is not None:      # dropped samples: the half is the identity, their tokens contribute nothing to the MLP's gradients
         assert torch.equal(y[0], x[0].to(BF).float()) and torch.equal(gx[0], gy[0].to(BF).float())
+
+
+# ------------------------------------------------------------------------------------------------ fused attention half (C = 32 / 64)
+@pytest.mark.parametrize("Cc,heads,B,H,W,scaled", [(32, 1, 2, 9, 10, True), (64, 2, 3, 8, 6, True), (32, 1, 2, 14, 7, False),
+                                                  (64, 2, 2, 5, 9, False), (32, 1, 4, 64, 48, True)])
+def test_fused_attention_half_forward_vs_oracle_and_unfused(N, Cc, heads, B, H, W, scaled):
+    """pk_attn_block_fwd (LN1 -> qkv -> window attention with rel-pos bias -> proj -> DropPath residual in one launch, pad tokens
+    attended) against the fp32 oracle block half and against the unfused kernel sequence; also the saved o / lse."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    from oracle import nets as onet
+    torch.manual_seed(Cc + H)
+    blk = HRFormerBlock(Cc, heads)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            p.copy_(q(p * 4) if p.dim() > 1 else q(p + 0.1 * torch.randn_like(p)))
+        blk.attn.relative_position_bias_table.copy_(q(torch.randn(169, heads) * 0.5))
+    x = q(torch.randn(B, H, W, Cc, generator=torch.Generator().manual_seed(1)) * 1.5)
+    s1 = torch.tensor([0.0, 1 / 0.9, 1 / 0.9, 1 / 0.9][:B]) if scaled else None
+    P = {"b." + k: v.detach().clone() for k, v in blk.state_dict().items()}
+    with torch.no_grad():
+        u = F.layer_norm(x, (Cc,), P["b.norm1.weight"], P["b.norm1.bias"], 1e-5)
+        tok, (Hp, Wp) = onet.to_windows(q(u))
+        a = onet.from_windows(onet.window_attention(tok, P, "b.attn", heads), B, H, W, Hp, Wp)
+        y_ref = x + (a if s1 is None else a * s1.view(B, 1, 1, 1))
+    blk = blk.to(DEV)
+    a_ = blk.attn
+    args = (blk.norm1.weight, blk.norm1.bias, a_.relative_position_bias_table, a_.qkv.weight, a_.qkv.bias, a_.proj.weight, a_.proj.bias,
+            None if s1 is None else s1.to(DEV), heads)
+    xd = x.to(DEV, BF)
+    with torch.no_grad(), N.use_weights(blk):
+        y, o, lse, _ = N.attn_half_fused_forward(xd, *args, save=True)
+        yu = N._AttnHalf.apply(xd, *args)
+        y2, o2, lse2, _ = N.attn_half_fused_forward(xd, *args, save=False)
+    torch.cuda.synchronize()
+    print("fused attn fwd vs fp32", err(C(y), y_ref), "vs unfused", err(C(y), C(yu)))
+    assert err(C(y), y_ref) < 1.5e-2 and err(C(y), C(yu)) < 1.5e-2
+    assert torch.equal(y, y2) and o2 is None and lse2 is None
+    assert torch.isfinite(o.float()).all() and torch.isfinite(lse).all()
+
+
+@pytest.mark.parametrize("Cc,heads,B,H,W,scaled", [(32, 1, 2, 9, 10, True), (64, 2, 3, 8, 6, True), (32, 1, 2, 14, 7, False),
+                                                  (64, 2, 2, 5, 9, False), (32, 1, 3, 32, 24, True)])
+def test_fused_attention_half_backward_vs_oracle_and_unfused(N, Cc, heads, B, H, W, scaled):
+    """pk_attn_block_bwd + the two weight-gradient GEMMs against autograd through the fp32 oracle half (LN output rounded to bf16 like
+    the kernels' operand) and against the unfused kernel sequence: dx, all seven parameter gradients incl. the rel-pos-bias table."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    from oracle import nets as onet
+    torch.manual_seed(Cc + H)
+    blk = HRFormerBlock(Cc, heads)
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            p.copy_(q(p * 4) if p.dim() > 1 else q(p + 0.1 * torch.randn_like(p)))
+        blk.attn.relative_position_bias_table.copy_(q(torch.randn(169, heads) * 0.5))
+    x = q(torch.randn(B, H, W, Cc, generator=torch.Generator().manual_seed(1)) * 1.5)
+    gy = q(torch.randn(B, H, W, Cc, generator=torch.Generator().manual_seed(2)))
+    s1 = torch.tensor([0.0, 1 / 0.9, 1 / 0.9, 1 / 0.9][:B]) if scaled else None
+    names = ["norm1.weight", "norm1.bias", "attn.relative_position_bias_table", "attn.qkv.weight", "attn.qkv.bias", "attn.proj.weight", "attn.proj.bias"]
+    P = {"b." + k: v.detach().clone().requires_grad_(k in names) for k, v in blk.state_dict().items()}
+    xr = x.clone().requires_grad_(True)
+    u = F.layer_norm(xr, (Cc,), P["b.norm1.weight"], P["b.norm1.bias"], 1e-5)
+    tok, (Hp, Wp) = onet.to_windows(u)
+    a = onet.from_windows(onet.window_attention(tok, P, "b.attn", heads), B, H, W, Hp, Wp)
+    y_ref = xr + (a if s1 is None else a * s1.view(B, 1, 1, 1))
+    y_ref.backward(gy)
+    blk = blk.to(DEV)
+    a_ = blk.attn
+    args = lambda: (blk.norm1.weight, blk.norm1.bias, a_.relative_position_bias_table, a_.qkv.weight, a_.qkv.bias, a_.proj.weight, a_.proj.bias,
+                    None if s1 is None else s1.to(DEV), heads)
+    out = {}
+    for mode in ("fused", "unfused"):
+        for p in blk.parameters():
+            p.grad = None
+        xd = x.to(DEV, BF).requires_grad_(True)
+        with N.use_weights(blk):
+            y = N._AttnHalfFused.apply(xd, *args()) if mode == "fused" else N._AttnHalf.apply(xd, *args())
+            y.backward(gy.to(DEV, BF))
+        torch.cuda.synchronize()
+        out[mode] = (C(y), C(xd.grad), {k: C(p.grad) for k, p in blk.named_parameters() if p.grad is not None})
+    y, gx, gp = out["fused"]
+    rep = {"y": err(y, y_ref.detach()), "gx": err(gx, xr.grad)}
+    for k in names:
+        rep["g." + k] = err(gp[k], P["b." + k].grad)
+    yu, gxu, gpu_ = out["unfused"]
+    repu = {"y": err(y, yu), "gx": err(gx, gxu)}
+    for k in names:
+        repu["g." + k] = err(gp[k], gpu_[k])
+    print("fused attn vs fp32   ", {k: round(v, 4) for k, v in rep.items()})
+    print("fused attn vs unfused", {k: round(v, 4) for k, v in repu.items()})
+    assert set(gp) == set(names)
+    # vs fp32: q, k, v, P, dS, dO are bf16 MFMA operands in both kernel paths (weights x4 make the softmax peaked): 3e-2 norm-wise,
+    # the bar of the block-level golden tests; the two kernel paths round at the same places and agree to 2e-2
+    assert all(v < 3e-2 for v in rep.values()), rep
+    assert all(v < 2e-2 for v in repu.values()), repu

@@ -1,13 +1,17 @@
 #!/usr/bin/env python3
 """Headline benchmark: training images/sec (fwd + bwd + AdamW step), HRFormer-small + fusion head, 256x192, bf16.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]        # N>1: launched by torch.distributed.run, one rank per GPU
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config NAME]
 
-Prints ONE JSON line on rank 0 (contract in the task statement).  Synthetic device-resident batches (SURVEY §8d,
-seed 1234+rank), B=64 per GPU (weak scaling), DropPath on, BN in train mode, every parameter updated.
-Extra objects: `roofline` (dominant hand-written HIP kernel, timed live with HIP events on its launch stream),
-`cpu_baseline` (the CPU oracle = parity-pinned port of the reference, timed on this host's cores, rank 0 / N=1 only),
-`--gpus N` without a torchrun environment starts N fresh ranks itself (one child process per GPU).
+`--gpus N` without a torchrun environment starts N fresh ranks itself (one child process per GPU); under
+`python -m torch.distributed.run --nproc-per-node N` it reads RANK / LOCAL_RANK / WORLD_SIZE.  Rank 0 prints ONE JSON line
+(contract in the task statement).  Synthetic device-resident batches (seed 1234+rank), weak scaling (fixed per-GPU batch),
+DropPath on, BN in train mode, every parameter updated.  Extra objects on the line:
+  `roofline`      the dominant hand-written kernel of the step AND a `table` with the top aggregate kernels of the rocprof trace
+                  (profiles/), each on its dominant shape, each timed live with HIP events on the launch stream;
+  `cpu_baseline`  the CPU oracle (parity-pinned port of the reference) timed on this host's cores (rank 0, N=1 only).
+Other BASELINE.json configs (not the headline metric): --config hrnet_w32_384 (cfg 4: HRNet-W32 heatmap head, 384x288, training) and
+--config hrformer_base_infer (cfg 5: HRFormer-base + fusion head, K=13, 384x288, flip-test inference, hipGraph replay).
 """
 import argparse
 import json
@@ -26,11 +30,19 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 def log(msg):
     print(f"# [{time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
-HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec
+
+HBM_PEAK_GBS = 8000.0           # MI355X_MICROARCH.md: 8 TB/s spec
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
 
-PER_GPU_BATCH = 64
-INPUT_SIZE, HEATMAP_SIZE, K = (192, 256), (48, 64), 17
+CONFIGS = {
+    "hrformer_small": dict(preset="hrformer_small", batch=64, mode="train", metric="images/sec (train fwd+bwd) HRFormer-S 256x192",
+                           workload="HRFormer-small + fusion head, 256x192 -> 64x48, K=17, train step fwd+bwd+AdamW, DropPath 0.1, BN train"),
+    "hrnet_w32_384": dict(preset="hrnet_w32", batch=32, mode="train", metric="images/sec (train fwd+bwd) HRNet-W32 384x288",
+                          workload="HRNet-W32 + heatmap head (KeypointMSELoss), 384x288 -> 96x72, K=17, train step fwd+bwd+AdamW, BN train"),
+    "hrformer_base_infer": dict(preset="preemie", batch=32, mode="infer", metric="images/sec (flip-test inference) HRFormer-B 384x288",
+                                workload="HRFormer-base + fusion head, K=13, 384x288 -> 96x72, flip-test inference (2 forwards + flip merge + decode), "
+                                         "8-aligned padded twin"),
+}
 
 
 def time_kernel(fn, iters=20, warmup=3):
@@ -47,53 +59,152 @@ def time_kernel(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def roofline_of_dominant_kernel(model):
-    """Dominant kernel of the step (rocprof, profiles/): k_igemm2<256,128,2,2,32> on the fusion head's 3x3 256->256 convs at
-    64x48 (fusion_head.py:215,224,235): 12 launches per step (forward + data-gradient), MFMA-bound.
-    Algorithmic flops per launch = 2*M*N*K = 2 * (B*64*48) * 256 * (9*256) = 232 GFLOP at B=64 (3.62 GFLOP/img)."""
-    from infantposeestimation_gaussianbias_amd import nnops
-    conv = model.head.shared_layers["3"]
-    B, H, W, C = PER_GPU_BATCH, HEATMAP_SIZE[1], HEATMAP_SIZE[0], conv.weight.shape[1]
-    x = torch.randn(B, H, W, C, device=conv.weight.device).to(torch.bfloat16)
-    with nnops.use_weights(model) as wc:
-        wf = wc.fwd[id(conv.weight)]
-        sec = time_kernel(lambda: nnops._conv_raw(x, wf, conv.weight.shape[0], 3, 1, True))
-    flops = 2.0 * B * H * W * conv.weight.shape[0] * 9 * C
-    achieved = flops / sec / 1e12
-    # HBM/fabric bytes per launch of this kernel: PMC counters need rocprofv3, so they are collected offline
-    # (scripts/gpu_pmc_traffic.sh, separate FETCH_SIZE / WRITE_SIZE passes, gfx950 correction applied) and committed
+def _entry(kernel, what, bound, sec, flops=None, bytes_=None, traffic=None, launches=None):
+    if bound == "mfma":
+        ach, peak, unit = flops / sec / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
+    else:
+        ach, peak, unit = bytes_ / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+    e = {"kernel": kernel, "shape": what, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
+         "traffic": traffic, "us_per_launch": round(sec * 1e6, 1)}
+    if flops:
+        e["algorithmic_flops"] = flops
+    if bytes_:
+        e["algorithmic_bytes"] = bytes_
+    if launches:
+        e["launches_per_step"] = launches
+    return e
+
+
+def roofline_table(model, B):
+    """The top aggregate kernels of the step (profiles/r02_trace_summary_*.txt), each on its dominant shape, timed live here.
+    Algorithmic work: GEMM-shaped kernels 2*M*N*K flops vs the dense bf16 MFMA peak; the shallow token GEMMs and the
+    fused block kernels are HBM-bound: bytes = every operand read once + every result written once."""
+    from infantposeestimation_gaussianbias_amd import _lib, nnops
+    from infantposeestimation_gaussianbias_amd._lib import call, stream_ptr
+    dev = next(model.parameters()).device
+    BF = torch.bfloat16
+    H, W = 64, 48
+    M = B * H * W
+    out = []
     traffic = None
     try:
         with open(os.path.join(ROOT, "profiles", "r01_pmc_head_conv_traffic.json")) as f:
-            traffic = round(json.load(f)["traffic_bytes_per_launch"])
+            traffic = round(json.load(f)["traffic_bytes_per_launch"])      # PMC passes are offline (scripts/gpu_pmc_traffic.sh); kernel unchanged since
     except (OSError, KeyError, ValueError):
         pass
-    return {"kernel": "k_igemm2<256,128,2,2,32> (head conv3x3 256->256 @64x48, fwd + BN-stat epilogue)", "bound": "mfma",
-            "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4),
-            "traffic": traffic, "traffic_unit": "bytes/launch (L2-miss traffic incl. Infinity-Cache hits; algorithmic 202.5e6)",
-            "us_per_launch": round(sec * 1e6, 1), "algorithmic_flops": flops}
+    with nnops.use_weights(model) as wc:
+        # 1. head conv 3x3 256->256 @64x48 (fusion_head.py:215,224,235), forward with the BN-statistics epilogue: 12 launches per step (fwd + dgrad)
+        conv = model.head.shared_layers["3"]
+        C = conv.weight.shape[1]
+        x = torch.randn(B, H, W, C, device=dev).to(BF)
+        g = torch.randn(B, H, W, C, device=dev).to(BF)
+        wf = wc.fwd[id(conv.weight)]
+        flops = 2.0 * M * conv.weight.shape[0] * 9 * C
+        sec = time_kernel(lambda: nnops._conv_raw(x, wf, conv.weight.shape[0], 3, 1, True))
+        out.append(_entry("k_igemm2<256,128,2,2,32>", "head conv3x3 256->256 @64x48, fwd + BN-stat epilogue", "mfma", sec, flops=flops,
+                          bytes_=2.0 * (2 * M * C) + 2 * 9 * C * C, traffic=traffic, launches=8))
+        # 2. its weight gradient: k_wgrad2<128,128,32> (5 launches per step on the head's 3x3 convs)
+        sec = time_kernel(lambda: nnops._wgrad(x, g, C, C, 3, 1, (B, H, W, H, W)))
+        out.append(_entry("k_wgrad2<128,128,32> (+ slab reduce)", "head conv3x3 256->256 @64x48 weight gradient", "mfma", sec, flops=flops,
+                          bytes_=2.0 * (2 * M * C), launches=73))
+        # 3. k_wgrad2<64,64,32>: dominant shape = qkv weight gradient of the branch-0 blocks (tokens x 96 x 32)
+        Mw = B * 70 * 49
+        u, dq = torch.randn(Mw, 32, device=dev).to(BF), torch.randn(Mw, 96, device=dev).to(BF)
+        sec = time_kernel(lambda: nnops._wgrad(u, dq, 96, 32, 1, 1, None, M=Mw))
+        out.append(_entry("k_wgrad2<64,64,32> (+ slab reduce)", "qkv weight gradient, branch 0: 219520 tokens x 96 x 32", "hbm", sec,
+                          flops=2.0 * Mw * 96 * 32, bytes_=2.0 * Mw * (96 + 32), launches=130))
+        # 4. k_igemm2<128,64,4,1,64>: dominant shape = 3x3 conv 64->64 @64x48 (layer1 / transition convs), forward with BN statistics
+        x64 = torch.randn(B, H, W, 64, device=dev).to(BF)
+        w64 = torch.randn(64, 9, 64, device=dev).to(BF)
+        sec = time_kernel(lambda: nnops._conv_raw(x64, w64, 64, 3, 1, True))
+        out.append(_entry("k_igemm2<128,64,4,1,64>", "conv3x3 64->64 @64x48 fwd + BN-stat epilogue", "mfma", sec, flops=2.0 * M * 64 * 9 * 64,
+                          bytes_=2.0 * (2 * M * 64), launches=76))
+        # 5./6. the fused block halves of branch 0 (C = 32): bytes = x in + y out (forward), x + dy in, dx out (backward)
+        blk = model.backbone.stage2[0].branches[0][0]
+        xb = torch.randn(B, H, W, 32, device=dev).to(BF)
+        gy = torch.randn(B, H, W, 32, device=dev).to(BF)
+        s = torch.ones(B, device=dev)
+        m, a = blk.mlp, blk.attn
+        if nnops.fused_mlp_enabled(32):
+            with torch.no_grad():
+                sec = time_kernel(lambda: nnops._MlpHalfFused.apply(xb, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
+                                                                    m.fc2.bias, s))
+            out.append(_entry("k_mlp_fwd<32>", "LN2+fc1+GELU+fc2+residual, 196608 tokens x 32 (hidden 128 in registers)", "hbm", sec,
+                              flops=16.0 * M * 32 * 32, bytes_=4.0 * M * 32, launches=14))
+        if nnops.fused_attn_enabled(32, 1):
+            aargs = (blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, s, 1)
+            y, o, lse, amap = nnops.attn_half_fused_forward(xb, *aargs, save=True)
+            nw = amap.numel() // 49
+            nb = _lib.lib.pk_attn_block_blocks(nw)
+            lnp, rpb = torch.empty(nb * 64, device=dev), torch.empty(nb * 4 * 169, device=dev)
+            dx, dqkv, u_w = torch.empty_like(xb), torch.empty(nw * 49, 96, device=dev, dtype=BF), torch.empty(nw * 49, 32, device=dev, dtype=BF)
+            sec = time_kernel(lambda: call("pk_attn_block_bwd", gy, xb, amap, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table,
+                                           wc.fwd[id(a.qkv.weight)], a.qkv.bias, wc.dgrad[id(a.qkv.weight)], wc.dgrad[id(a.proj.weight)], s, o, lse,
+                                           dx, dqkv, u_w, lnp, rpb, nw, nw // B, 1, 32, 1e-5, stream_ptr()))
+            out.append(_entry("k_attn_bwd<32>", "attention-half backward, 4480 windows x 49 tokens x 32 (dx + dqkv + u)", "hbm", sec,
+                              bytes_=2.0 * (3 * M * 32 + nw * 49 * (32 + 96 + 32)), launches=14))
+    return out
 
 
-def cpu_baseline():
-    """CPU oracle train step (B=8: ~2 s/step on 8 cores -> 1 warm-up + 3 timed steps stays within ~10-30 s)."""
-    import json as _json
+def cpu_baseline(cfg_name, c):
+    """CPU oracle train step (B=8: ~2 s/step on 16 cores -> 2 warm-up + 5 timed steps)."""
     from oracle import train_step as ots
     with open(os.path.join(ROOT, "tests", "golden", "state_keys.json")) as f:
-        keys = _json.load(f)
-    # the GPU box gives one job a 16-CPU share of a much larger host: use the cores we may actually run on
-    cores = max(1, min(len(os.sched_getaffinity(0)), 16))
-    ips, threads = ots.time_train_steps(keys["hrformer_small_fusion"], keys["hrformer_small_fusion#params"], B=8, steps=3, warmup=1,
-                                        input_size=INPUT_SIZE, heatmap_size=HEATMAP_SIZE, K=K, threads=cores)
+        keys = json.load(f)
+    cores = max(1, min(len(os.sched_getaffinity(0)), 16))      # the GPU box gives one job a 16-CPU share of a much larger host
+    if cfg_name != "hrformer_small":
+        return None
+    ips, threads = ots.time_train_steps(keys["hrformer_small_fusion"], keys["hrformer_small_fusion#params"], B=8, steps=5, warmup=2,
+                                        input_size=c["input"], heatmap_size=c["heatmap"], K=c["K"], threads=cores)
     return {"value": round(ips, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "HRFormer-small fusion 256x192 train step (fwd+bwd+AdamW), fp32 PyTorch-CPU oracle, B=8, 1 warm-up + 3 timed steps"}
+            "sample": "HRFormer-small fusion 256x192 train step (fwd+bwd+AdamW), fp32 PyTorch-CPU oracle, B=8, 2 warm-up + 5 timed steps"}
+
+
+class InferRunner:
+    """Flip-test inference as one replayed hipGraph (static input buffer); falls back to eager launches when capture is refused."""
+
+    def __init__(self, model, x, pairs):
+        self.model, self.x, self.pairs = model, x.clone(), pairs
+        self.graph, self.out = None, None
+        with torch.no_grad():
+            for _ in range(2):
+                self.out = model.inference(self.x, flip=True, flip_pairs=pairs)
+        torch.cuda.synchronize()
+        if os.environ.get("POSE_GRAPH", "1") != "0":
+            try:
+                from infantposeestimation_gaussianbias_amd import dispatch
+                dispatch.set_streams(False)
+                s = torch.cuda.Stream()
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s), torch.no_grad():
+                    self.model.inference(self.x, flip=True, flip_pairs=pairs)       # warm the side stream's allocator pool
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s):
+                        self.out = self.model.inference(self.x, flip=True, flip_pairs=pairs)
+                torch.cuda.current_stream().wait_stream(s)
+                self.graph = g
+            except Exception as e:       # noqa: BLE001  (capture refusals differ by ROCm version; the eager path is always valid)
+                log(f"inference capture failed ({type(e).__name__}: {e}); timing eager launches")
+                torch.cuda.synchronize()
+
+    def step(self, x):
+        if self.graph is not None:
+            self.x.copy_(x, non_blocking=True)
+            self.graph.replay()
+            return self.out
+        with torch.no_grad():
+            return self.model.inference(x, flip=True, flip_pairs=self.pairs)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="hrformer_small", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--eager", action="store_true",
                     help="launch every kernel from the host each step instead of replaying the captured hipGraph")
     ap.add_argument("--single-stream", action="store_true", help="do not run the resolution branches on concurrent HIP streams")
@@ -126,31 +237,41 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    from infantposeestimation_gaussianbias_amd import dispatch, engine, nnops
+    from infantposeestimation_gaussianbias_amd import _lib, dispatch, engine
     from infantposeestimation_gaussianbias_amd.configs import get_config
     from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
     from infantposeestimation_gaussianbias_amd.models import build_model
 
+    c = dict(CONFIGS[args.config])
     torch.manual_seed(42)
-    cfg = get_config("hrformer_small")
-    cfg.train.batch_size = PER_GPU_BATCH
+    cfg = get_config(c["preset"])
+    c.update(input=tuple(cfg.data.input_size), heatmap=tuple(cfg.data.heatmap_size), K=cfg.data.num_keypoints)
+    B = c["batch"]
+    cfg.train.batch_size = B
     model = build_model(cfg).to(dev)
-    # default: the whole step (zero_grad + fwd + bwd + AdamW; with N>1 the RCCL all-reduce and AdamW stay outside) is one
-    # hipGraph whose branches fork/join across HIP streams
     use_graph = not (args.eager or os.environ.get("POSE_GRAPH", "1") == "0")
     streams = not (args.single_stream or os.environ.get("POSE_STREAMS", "1") == "0")
     if not streams:
         os.environ["POSE_STREAMS"] = "0"
-    trainer = engine.Trainer(model, cfg, iters_per_epoch=1000, use_graph=use_graph, graph_warmup=2, graph_streams=streams)
-    batch = synthetic_batch(PER_GPU_BATCH, INPUT_SIZE, HEATMAP_SIZE, K, 2.0, dev, seed=1234 + rank)
-    args.warmup = max(args.warmup, 4) if use_graph else args.warmup      # 2 eager steps + capture + 1 replay before timing
+    batch = synthetic_batch(B, c["input"], c["heatmap"], c["K"], cfg.data.sigma, dev, seed=1234 + rank)
+    calls_per_step, launch = None, None
 
-    from infantposeestimation_gaussianbias_amd import _lib
-    out, calls_per_step = None, None
+    if c["mode"] == "train":
+        # default: the whole step (zero_grad + fwd + bwd + gradient exchange + AdamW) is one hipGraph whose branches fork/join across HIP streams
+        trainer = engine.Trainer(model, cfg, iters_per_epoch=1000, use_graph=use_graph, graph_warmup=2, graph_streams=streams)
+        args.warmup = max(args.warmup, 4) if use_graph else args.warmup      # 2 eager steps + capture + 1 replay before timing
+        step = lambda: trainer.step(batch)
+    else:
+        model.eval()
+        dispatch.set_streams(False)
+        runner = InferRunner(model, batch["img"], cfg.data.flip_pairs or [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12)])
+        step = lambda: runner.step(batch["img"])
+
+    out = None
     for i in range(args.warmup):
         t_w = time.perf_counter()
         c0 = _lib.CALLS[0]
-        out = trainer.step(batch)
+        out = step()
         if i == 1:
             calls_per_step = _lib.CALLS[0] - c0      # second eager warm-up step: every kernel sequence issued from the host
         if rank == 0 and i < 3:
@@ -161,7 +282,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = trainer.step(batch)
+        out = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -171,29 +292,39 @@ def main():
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    loss = float(out["loss"].detach())
+    if c["mode"] == "train":
+        final = float(out["loss"].detach())
+        launch = ("hipGraph replay" if trainer._graph is not None else "eager launches") + \
+                 (", branches on concurrent HIP streams" if dispatch.streams_enabled() else ", single stream")
+        if world > 1:
+            launch += f", gradient all-reduce (RCCL) {'inside the graph' if getattr(trainer, '_graph_has_comm', False) else 'between replays'}"
+    else:
+        kp, sc = out
+        final = float(torch.isfinite(kp).all())
+        launch = "hipGraph replay" if runner.graph is not None else "eager launches"
 
     if rank == 0:
-        log(f"timed region: {dt:.3f} s for {args.steps} steps -> {PER_GPU_BATCH * world * args.steps / dt:.1f} img/s")
-        roof = roofline_of_dominant_kernel(model)
-        log(f"roofline kernel timed: {roof}")
+        log(f"timed region: {dt:.3f} s for {args.steps} steps -> {B * world * args.steps / dt:.1f} img/s")
+        roof = None
+        if args.config == "hrformer_small" and not args.no_roofline:
+            table = roofline_table(model, B)
+            roof = dict(table[0])
+            roof["table"] = table
+            for e in table:
+                log(f"roofline: {e['kernel']:40s} {e['us_per_launch']:8.1f} us  {e['achieved']:8.1f} {e['unit']} = {e['frac'] * 100:5.1f} % of {e['bound']} peak")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline()
+            cpu = cpu_baseline(args.config, c)
             log(f"cpu baseline: {cpu}")
         line = {
-            "metric": "images/sec (train fwd+bwd) HRFormer-S 256x192", "value": round(PER_GPU_BATCH * world * args.steps / dt, 2),
+            "metric": c["metric"], "value": round(B * world * args.steps / dt, 2),
             "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "HRFormer-small + fusion head, 256x192 -> 64x48, K=17, train step fwd+bwd+AdamW, DropPath 0.1, BN train",
-                       "global_batch": PER_GPU_BATCH * world, "per_gpu_batch": PER_GPU_BATCH, "parallelism": f"dp{world}",
-                       "launch": ("hipGraph replay" if trainer._graph is not None else "eager launches") +
-                       (", branches on concurrent HIP streams" if dispatch.streams_enabled() else ", single stream")},
-            "roofline": roof, "cpu_baseline": cpu, "final_loss": round(loss, 5),
+            "config": {"workload": c["workload"], "global_batch": B * world, "per_gpu_batch": B, "parallelism": f"dp{world}", "launch": launch},
+            "roofline": roof, "cpu_baseline": cpu, ("final_loss" if c["mode"] == "train" else "outputs_finite"): round(final, 5),
             "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
-            "c_abi_calls_per_step": calls_per_step,
-            "backend": dispatch.backend_name(model),
+            "c_abi_calls_per_step": calls_per_step, "backend": dispatch.backend_name(model),
         }
         print(json.dumps(line))
     if world > 1:

@@ -64,7 +64,7 @@ def ops():
 
 
 # the network ops themselves (they refuse to run outside a scope: nnops._wc() raises without an active weight cache)
-from .nnops import conv_bn_act, drop_scales, exchange, head_out, to_features, window_block  # noqa: E402,F401
+from .nnops import backward_milestone, conv_bn_act, drop_scales, exchange, head_out, to_features, window_block  # noqa: E402,F401
 
 
 def to_public(x):

@@ -209,12 +209,15 @@ class WarmupMultiStepLR:
 class GradientExchange:
     """Data-parallel gradient sum over ranks on the flat gradient buffer (RCCL `nccl` backend on GPUs, gloo on CPU).
 
-    Buckets are contiguous slices of the flat buffer, built from the END (backward produces the last layers first).
-    Default (`overlap=False`): all buckets are all-reduced right after backward, on the stream backward joined into.
-    HRFormer-small's whole gradient is 46 MB (~0.5 ms over xGMI, <2 % of a 35 ms step), and with the resolution
-    branches running on concurrent HIP streams a bucket can complete on a different stream than the one its hook fires
-    on, so hook-driven overlap is only offered (`overlap=True`) for single-stream autograd: each bucket's all-reduce is
-    then launched from a post-accumulate hook as soon as all of its *active* parameters have their gradient."""
+    Buckets are contiguous slices of the flat buffer, built from the END (backward produces the last layers first).  A bucket's
+    all-reduce is launched asynchronously (RCCL runs it on its own stream) as soon as every ACTIVE parameter in it has its final
+    gradient of the step, so the exchange of the head's / late stages' gradients overlaps with the rest of backward:
+      * gradient-sink mode (FlatAdamW(direct_grads=True), the Trainer's default): `flush_ready()` is called from backward
+        MILESTONES (nnops.backward_milestone: hooks on the stage-boundary tensors, fired when backward has passed them) after the
+        postponed slab reductions registered so far have been run; readiness = the parameter's sink was stored to this step;
+      * plain autograd mode (`overlap=True`): post-accumulate hooks count a bucket's gradients.
+    `finish()` launches whatever is left and waits.  Parameters that never receive a gradient (41 tensors for HRFormer-small,
+    SURVEY §8e) are skipped consistently on all ranks (the active set is structural)."""
 
     def __init__(self, opt: FlatAdamW, bucket_mb: float = 16.0, group=None, overlap: bool = False):
         self.opt, self.group, self.overlap = opt, group, overlap
@@ -224,6 +227,8 @@ class GradientExchange:
         self._hooks = []
         self._pending = []
         self._armed = False
+        self.suspended = False          # True while a hipGraph without collectives is being captured: milestones must not launch any
+        self.launched_early = 0         # buckets launched from milestones / hooks in the last step (observability, tests)
 
     def broadcast_initial_state(self):
         if self.world == 1:
@@ -242,12 +247,13 @@ class GradientExchange:
             if hi - cur >= self.bucket_elems or i == 0:
                 plan.append((cur, hi, members))
                 hi, members = cur, []
-        self.buckets = [{"lo": lo, "hi": hi_, "need": sum(1 for i in m if opt.active[i]), "got": 0} for lo, hi_, m in plan]
+        self.buckets = [{"lo": lo, "hi": hi_, "members": [i for i in m if opt.active[i]], "need": sum(1 for i in m if opt.active[i]), "got": 0}
+                        for lo, hi_, m in plan]
         owner = {}
         for b, (_, _, m) in enumerate(plan):
             for i in m:
                 owner[i] = b
-        if self.overlap:
+        if self.overlap and not opt.direct_grads:
             for i, p in enumerate(opt.params):
                 if opt.active[i]:
                     self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(owner[i])))
@@ -257,13 +263,28 @@ class GradientExchange:
         def hook(_param):
             bk = self.buckets[b]
             bk["got"] += 1
-            if bk["got"] == bk["need"]:
+            if bk["got"] == bk["need"] and not self.suspended:
+                self.launched_early += 1
                 self._launch(bk)
         return hook
 
     def _launch(self, bk):
         bk["got"] = -1     # launched
         self._pending.append(dist.all_reduce(self.opt.grad[bk["lo"]:bk["hi"]], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def flush_ready(self):
+        """Gradient-sink mode: launch, in backward order, every bucket whose active parameters have all been stored to this step.
+        The caller has run nnops.finalize_deferred() first, so a stored-to sink holds its final value."""
+        if self.world == 1 or not self._armed or self.suspended or not self.opt.direct_grads:
+            return
+        from . import nnops as _nn
+        for bk in self.buckets:
+            if bk["got"] == -1:
+                continue
+            if not all(_nn.sink_written(self.opt.params[i]) for i in bk["members"]):
+                break               # buckets are ordered by backward time: later ones cannot be complete either
+            self.launched_early += 1
+            self._launch(bk)
 
     def finish(self):
         """Call after backward: flush buckets that did not fire (first step, or only inactive members), wait for all."""
@@ -273,12 +294,9 @@ class GradientExchange:
             self.opt.install_grad_views()
         if not self._armed:
             self._build()
-            for bk in self.buckets:        # first step ran without hooks: reduce everything now
+        for bk in self.buckets:
+            if bk["got"] != -1:
                 self._launch(bk)
-        else:
-            for bk in self.buckets:
-                if bk["got"] != -1:
-                    self._launch(bk)
         for w in self._pending:
             w.wait()
         self._pending.clear()
@@ -293,28 +311,32 @@ class GradientExchange:
 class Trainer:
     """One optimisation step of train.py::train_one_epoch (:169-187) without its per-step host syncs.
 
-    `use_graph=True` captures zero_grad + forward + backward (+ the optimiser when single-GPU) of a fixed-shape batch into
-    a hipGraph after `graph_warmup` eager steps and replays it: ~3 300 kernel launches per step become one graph launch,
-    which removes the host as the bottleneck.  With N>1 ranks the gradient all-reduce and the optimiser run eagerly
-    between replays (RCCL is kept out of the capture).  The LR is written to a device scalar before each replay, so the
-    per-iteration schedule advances normally.  Batches are copied into static input buffers."""
+    `use_graph=True` captures zero_grad + forward + backward + gradient exchange + optimiser of a fixed-shape batch into a hipGraph
+    after `graph_warmup` eager steps and replays it: ~1 300 kernel launches per step become one graph launch, which removes the
+    host as the bottleneck.  With N>1 ranks over RCCL the bucketed all-reduces are captured too: they are issued from backward
+    milestones on RCCL's own stream, so inside the replayed graph they run beside the remaining backward kernels, and AdamW follows
+    in the same graph.  When the collectives cannot be captured (gloo, or a capture the runtime refuses) the graph holds
+    zero_grad + forward + backward only and the exchange + AdamW run between replays.  The LR is written to a device scalar before
+    each replay, so the per-iteration schedule advances normally.  Batches are copied into static input buffers."""
 
-    def __init__(self, model, cfg, iters_per_epoch: int, bucket_mb: float = 16.0, use_graph: bool = False, graph_warmup: int = 3,
-                 overlap_comm: bool = False, graph_streams: bool = False):
+    def __init__(self, model, cfg, iters_per_epoch: int, bucket_mb: float = 8.0, use_graph: bool = False, graph_warmup: int = 3,
+                 overlap_comm: bool = True, graph_streams: bool = False):
         self.model, self.cfg = model, cfg
         self.overlap_comm = overlap_comm
-        # concurrent branch streams: on for eager steps (unless hook-driven comm overlap needs single-stream autograd);
-        # inside a captured graph only on request (fork/join capture across streams, see scripts/gpu_graph_streams.py)
-        self._want_streams = graph_streams if use_graph else (not overlap_comm)
+        # concurrent branch streams: on for eager steps; inside a captured graph only on request (fork/join capture across
+        # streams, see scripts/gpu_graph_streams.py)
+        self._want_streams = graph_streams if use_graph else True
         self._region = graph_streams               # with use_graph=False: eager launches, same autograd structure as the graph
         t = cfg.train
         if t.optimizer != "AdamW":
             raise ValueError(f"Unknown optimizer: {t.optimizer}")   # the fused kernel implements the reference default only
-        # gradients are stored directly by the backward kernels unless autograd hooks are wanted (overlap_comm)
-        self.opt = FlatAdamW(model, t.lr, tuple(t.betas), 1e-8, t.weight_decay, direct_grads=not overlap_comm)
+        # gradients are stored directly by the backward kernels (gradient sinks); the exchange is driven by backward milestones
+        self.opt = FlatAdamW(model, t.lr, tuple(t.betas), 1e-8, t.weight_decay, direct_grads=True)
         self.sched = WarmupMultiStepLR(self.opt, t, iters_per_epoch)
         self.comm = GradientExchange(self.opt, bucket_mb, overlap=overlap_comm)
         self.comm.broadcast_initial_state()
+        if self.comm.world > 1 and overlap_comm:
+            nnops.set_milestone_callback(self._milestone)
         # >= 2 eager steps before capture: step 1 installs the gradient sinks, step 2 builds the descriptor tables that depend on
         # them (deferred reductions, padded-twin extraction) -- table uploads are host->device copies and cannot be captured
         self.use_graph, self.graph_warmup = use_graph, max(2, graph_warmup)
@@ -326,6 +348,14 @@ class Trainer:
         self._graph = None
         self._static = None
         self._static_out = None
+        self._graph_has_opt = self._graph_has_comm = False
+
+    def _milestone(self):
+        """Backward has passed a stage boundary: everything registered so far belongs to layers whose backward is complete."""
+        if self.comm.suspended or not self.comm._armed:
+            return
+        nnops.finalize_deferred()
+        self.comm.flush_ready()
 
     # -- eager path --------------------------------------------------------------------------------------------
     def _fwd_bwd(self, batch):
@@ -343,6 +373,7 @@ class Trainer:
     def _eager_step(self, batch):
         if not self.model.training:
             self.model.train()
+        self.comm.launched_early = 0
         out = self._fwd_bwd(batch)
         self.comm.finish()
         self.opt.step(self.comm.grad_scale)
@@ -350,28 +381,53 @@ class Trainer:
         return out
 
     # -- graph path --------------------------------------------------------------------------------------------
+    def _comm_capturable(self):
+        return (self.comm.world > 1 and dist.get_backend(self.comm.group) == "nccl" and os.environ.get("POSE_GRAPH_COMM", "1") != "0")
+
     def _capture(self, batch):
         keys = [k for k in ("img", "target", "target_weight", "keypoints") if batch.get(k) is not None]
         self._static = {k: batch[k].clone() for k in keys}
-        self._graph_has_opt = self.comm.world == 1
-        torch.cuda.synchronize()
-        mode = "global"
-        if self.comm.world > 1:
-            # The process group's watchdog thread polls the events of outstanding collectives (cudaEventQuery); under the
-            # default global capture mode such a call from another thread invalidates the capture.  All collectives have
-            # completed (synchronize above); give the watchdog one polling period to retire them, and only police the
-            # capturing threads' own calls.
-            import time
-            time.sleep(0.5)
-            mode = "thread_local"
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g, stream=self._stream, capture_error_mode=mode):
-            out = self._fwd_bwd(self._static)
-            if self._graph_has_opt:
-                self.opt.step(1.0)
-        if self._graph_has_opt:
-            self.opt.step_count -= 1          # the captured optimiser launch did not execute; _graph_step counts the replays
-        self._graph, self._static_out = g, out
+        world = self.comm.world
+        attempts = [True, False] if self._comm_capturable() else [world == 1]
+        for whole_step in attempts:
+            torch.cuda.synchronize()
+            mode = "global"
+            if world > 1:
+                # The process group's watchdog thread polls the events of outstanding collectives (cudaEventQuery); under the
+                # default global capture mode such a call from another thread invalidates the capture.  All collectives have
+                # completed (synchronize above); give the watchdog one polling period to retire them, and only police the
+                # capturing threads' own calls.
+                import time
+                time.sleep(0.5)
+                mode = "thread_local"
+            self.comm.suspended = world > 1 and not whole_step      # no collectives inside a forward+backward-only capture
+            steps_before = self.opt.step_count
+            g = torch.cuda.CUDAGraph()
+            try:
+                with torch.cuda.graph(g, stream=self._stream, capture_error_mode=mode):
+                    out = self._fwd_bwd(self._static)
+                    if whole_step:
+                        self.comm.finish()
+                        self.opt.step(self.comm.grad_scale)
+            except Exception as e:      # noqa: BLE001  (a refused RCCL capture must not end the run: fall back to exchange between replays)
+                if not (whole_step and world > 1):
+                    raise
+                import sys
+                print(f"# engine: capturing the step with its RCCL all-reduces failed ({type(e).__name__}: {e}); capturing forward+backward only",
+                      file=sys.stderr, flush=True)
+                self.opt.step_count = steps_before
+                self.comm._pending.clear()
+                for bk in self.comm.buckets:
+                    bk["got"] = 0
+                nnops._PENDING.clear()
+                continue
+            finally:
+                self.comm.suspended = False
+            if whole_step:
+                self.opt.step_count -= 1          # the captured optimiser launch did not execute; _graph_step counts the replays
+            self._graph, self._static_out = g, out
+            self._graph_has_opt, self._graph_has_comm = whole_step, whole_step and world > 1
+            break
         nnops.freeze_workspaces(self.model)   # the graph holds the slab-workspace pointers: they must not be reallocated
 
     def _graph_step(self, batch):
@@ -412,12 +468,6 @@ class Trainer:
                 torch.cuda.current_stream().wait_stream(self._stream)
                 return out
             self.model.train()
-            if self.comm.world > 1 and self.comm._armed:
-                for h in self.comm._hooks:        # hooks would fire inside the capture: reduce after the replay instead
-                    h.remove()
-                self.comm._hooks.clear()
-                for bk in self.comm.buckets:
-                    bk["need"] = -2               # never "complete" by counting; finish() flushes every bucket
             self._capture(batch)
             # the capture itself does not execute: run this step through the graph
         if any(k not in batch or batch[k] is None or batch[k].shape != v.shape for k, v in self._static.items()):

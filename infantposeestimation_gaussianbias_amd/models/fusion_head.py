@@ -76,15 +76,19 @@ class HeatmapRegressionHead(nn.Module):
         f = nnops.conv_bn_act(x, s["0"], s["1"], True, None, tr)
         f = nnops.conv_bn_act(f, s["3"], s["4"], True, None, tr)
 
-        def run(br, softplus=False):
-            t = nnops.conv_bn_act(f, br["0"], br["1"], True, None, tr)
-            return nnops.head_out(t, br["3"], softplus)
+        def make(br, softplus=False):
+            def run(ins):
+                t = nnops.conv_bn_act(ins[0], br["0"], br["1"], True, None, tr)
+                return nnops.head_out(t, br["3"], softplus)
+            return run
 
-        heatmaps = run(self.heatmap_branch)
-        offsets = run(self.offset_branch)
+        # the three branches are independent: on concurrent streams their small BatchNorm kernels (finalize, partial sums: a
+        # handful of workgroups each) hide under another branch's convolution instead of leaving the GPU idle
+        heatmaps, offsets, variances = nnops.parallel([make(self.heatmap_branch), make(self.offset_branch), make(self.variance_branch, True)],
+                                                      [[f], [f], [f]])
         B, _, H, W = offsets.shape
         return {"heatmaps": heatmaps, "offsets": offsets.view(B, self.num_keypoints, 2, H, W),
-                "variances": run(self.variance_branch, True), "fusion_weight": torch.sigmoid(self.fusion_weight)}
+                "variances": variances, "fusion_weight": torch.sigmoid(self.fusion_weight)}
 
     @torch.no_grad()
     def decode(self, outputs: Dict[str, torch.Tensor], apply_offset: bool = True) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -142,6 +142,9 @@ class HRFormer(nn.Module):
                 n = m.n_draws()
                 ys = m(ys, None if scales is None else scales[d:d + n])
                 d += n
+            # N > 1: once backward has passed this boundary the later stages' gradients are exchanged while the earlier stages still
+            # run backward (only output 0 of the last stage is consumed, hrformer.py:776 / hrnet.py:441)
+            nnops.backward_milestone(ys if s < 4 else ys[:1])
         return ys[0]
 
 

@@ -69,6 +69,9 @@ class HRNet(nn.Module):
             ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
             for m in getattr(self, f"stage{s}"):
                 ys = m(ys)
+            # N > 1: once backward has passed this boundary the later stages' gradients are exchanged while the earlier stages still
+            # run backward (only output 0 of the last stage is consumed, hrformer.py:776 / hrnet.py:441)
+            nnops.backward_milestone(ys if s < 4 else ys[:1])
         return ys[0]
 
 

@@ -157,6 +157,36 @@ def _reduce_now(rows, dev):
             t.record_stream(torch.cuda.current_stream())
 
 
+# ================================================================================================ backward milestones
+# A milestone is a set of tensors at a stage boundary of the forward pass; when backward has produced the gradient of every one
+# of them, all layers after the boundary have finished their backward.  engine.Trainer (N > 1 ranks) registers a callback that
+# runs the postponed slab reductions registered so far and launches the all-reduce of the gradient buckets that are complete,
+# so the exchange overlaps with the rest of backward.  Without a callback (single GPU, inference) milestones cost nothing.
+_MILESTONE_CB = [None]
+
+
+def set_milestone_callback(cb):
+    _MILESTONE_CB[0] = cb
+
+
+def backward_milestone(tensors):
+    cb = _MILESTONE_CB[0]
+    if cb is None or not torch.is_grad_enabled():
+        return
+    ts = [t for t in tensors if torch.is_tensor(t) and t.requires_grad]
+    if not ts:
+        return
+    left = [len(ts)]
+
+    def hook(_g):
+        left[0] -= 1
+        if left[0] == 0:
+            cb()
+
+    for t in ts:
+        t.register_hook(hook)
+
+
 # ================================================================================================ weight cache
 _PACK_DTYPE = np.dtype([("src", "<i8"), ("dst_off", "<i8"), ("N", "<i4"), ("C", "<i4"), ("T", "<i4"), ("mode", "<i4"),
                         ("Cp", "<i4"), ("Np", "<i4"), ("dst_numel", "<i8")])

@@ -352,8 +352,10 @@ class Trainer:
 
     def _milestone(self):
         """Backward has passed a stage boundary: everything registered so far belongs to layers whose backward is complete."""
-        if self.comm.suspended or not self.comm._armed:
+        if not self.comm._armed:
             return
+        # (also while a forward+backward-only graph is being captured: the partial reduction tables must be the ones the eager
+        # warm-up steps built -- a new table cannot be uploaded during capture; only the collectives are held back)
         nnops.finalize_deferred()
         self.comm.flush_ready()
 

@@ -1,7 +1,4 @@
-export POSE_FUSED_ATTN=32 POSE_FUSED_ATTN_EVAL=32,64
-cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-tag=crit
-timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 6 --warmup 4 --no-cpu-baseline > gpurun_out/prof_$tag.log 2>&1
-python scripts/trace_summary.py $(ls gpurun_out/prof_$tag/*/*kernel_trace.csv | head -1) 3 > gpurun_out/trace_summary_$tag.txt 2>&1
-rm -rf gpurun_out/prof_$tag
-tail -30 gpurun_out/trace_summary_$tag.txt
+bash scripts/gpu_round.sh r2b || exit 1
+timeout -k 10 300 python bench.py --config hrnet_w32_384 --steps 20 --warmup 5 > gpurun_out/bench_w32.json 2> gpurun_out/bench_w32.err; tail -c 700 gpurun_out/bench_w32.json; tail -3 gpurun_out/bench_w32.err
+timeout -k 10 300 python bench.py --config hrformer_base_infer --steps 20 --warmup 5 > gpurun_out/bench_base.json 2> gpurun_out/bench_base.err; tail -c 700 gpurun_out/bench_base.json; tail -3 gpurun_out/bench_base.err
+timeout -k 10 400 python bench.py > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err; tail -c 3000 gpurun_out/bench_full.json; grep roofline gpurun_out/bench_full.err

@@ -5,7 +5,7 @@ set -o pipefail
 tag=${1:-cur}
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"
-timeout -k 10 700 python -m pytest tests -m gpu -q --timeout 400 > gpurun_out/tests_$tag.log 2>&1; rc=$?
+timeout -k 10 600 python -m pytest tests -m gpu -q --timeout 200 > gpurun_out/tests_$tag.log 2>&1; rc=$?
 tail -4 gpurun_out/tests_$tag.log | cut -c1-300
 if [ $rc -ne 0 ]; then grep -n "^E  \|^FAILED" gpurun_out/tests_$tag.log | head -30; exit $rc; fi
 timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2 || exit 1

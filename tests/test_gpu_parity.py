@@ -724,6 +724,7 @@ def _dp_gpu_worker(rank, world, port, q, use_graph=False):
     tr._fwd_bwd(shard)                                       # second pass: same kernels as every later step (gradient sinks,
     local = tr.opt.grad.clone()                              # deferred slab reductions) -> bitwise comparable with the step below
     tr.comm.world = world_saved
+    tr.comm.finish()                                         # builds the buckets (and sums the probe gradients, which the step overwrites)
     # (the probe pass also advanced the BN running statistics; training-mode gradients do not depend on them)
     out = tr.step(shard)
     torch.cuda.synchronize()
@@ -746,10 +747,14 @@ def _run_two_ranks(use_graph):
     procs = [ctx.Process(target=_dp_gpu_worker, args=(r, 2, port, q, use_graph)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    try:
+        res = sorted([q.get(timeout=150) for _ in procs], key=lambda t: t[0])
+    finally:
+        for p in procs:
+            p.join(20)
+            if p.is_alive():            # a rank that died took its peer's collective with it: do not leave the survivor on the GPU
+                p.kill()
+    assert all(p.exitcode == 0 for p in procs)
     return res
 
 

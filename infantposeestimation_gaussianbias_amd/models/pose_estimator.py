@@ -105,15 +105,24 @@ class PoseEstimator(nn.Module):
         hm = out["heatmaps"]
         if flip and flip_pairs is not None:
             hm_f = self.forward(torch.flip(x, dims=[-1]))["heatmaps"]
-            partner = torch.arange(self.num_keypoints, dtype=torch.int32)
-            for a, b in flip_pairs:
-                partner[a], partner[b] = b, a
-            hm = hipops.flip_merge(hm, hm_f, partner.to(hm.device))
+            hm = hipops.flip_merge(hm, hm_f, self._flip_partner(flip_pairs, hm.device))
         if self.head_type == "fusion":
             o = dict(out)
             o["heatmaps"] = hm
             return self.head.decode(o, apply_offset=True)
         return self.decode_heatmaps(hm)
+
+    def _flip_partner(self, flip_pairs, device):
+        """int32 (K,) left/right partner of every keypoint, cached on the device (no host->device copy per call: inference is
+        hipGraph-capturable)."""
+        key = (tuple(tuple(p) for p in flip_pairs), str(device))
+        cache = self.__dict__.setdefault("_partner_cache", {})
+        if key not in cache:
+            partner = torch.arange(self.num_keypoints, dtype=torch.int32)
+            for a, b in flip_pairs:
+                partner[a], partner[b] = b, a
+            cache[key] = partner.to(device)
+        return cache[key]
 
     @staticmethod
     @torch.no_grad()

@@ -30,6 +30,35 @@ def bf16_round(t):
     return t.to(torch.bfloat16).to(t.dtype)
 
 
+class _StorageRound(torch.autograd.Function):
+    """bf16 storage emulation of one tensor: the value is rounded on the way forward and its gradient on the way back (the HIP path
+    keeps every activation AND every activation gradient in bf16 between kernels)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return bf16_round(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        return bf16_round(g)
+
+
+def bf16_storage(t):
+    return _StorageRound.apply(t) if t.requires_grad else bf16_round(t)
+
+
+def bf16_weights(P):
+    """The compute copies of the HIP path: conv / linear weights rounded to bf16 (with a straight-through gradient so the result can be
+    differentiated w.r.t. the fp32 masters); biases, norm affines, rel-pos tables and buffers stay fp32."""
+    out = {}
+    for k, v in P.items():
+        if v.is_floating_point() and v.dim() in (2, 4) and k.endswith(".weight"):
+            out[k] = v + (bf16_round(v.detach()) - v.detach())
+        else:
+            out[k] = v
+    return out
+
+
 # ------------------------------------------------------------------------------ conv / BN pieces
 def conv(x, P, key, stride=1, pad=None):
     w = P[key + ".weight"]
@@ -39,18 +68,21 @@ def conv(x, P, key, stride=1, pad=None):
 
 
 def batchnorm(x, P, key, ctx):
-    """Train: biased batch variance normalises, running_var gets the unbiased one, momentum 0.1, eps 1e-5."""
+    """Train: biased batch variance normalises, running_var gets the unbiased one, momentum 0.1, eps 1e-5.
+    With a storage-rounding hook (ctx.q) the statistics are those of the fp32 conv output while the normalised tensor is the
+    rounded one -- the HIP path takes the sums from the GEMM's fp32 accumulators and stores the raw output in bf16."""
     g, b = P[key + ".weight"], P[key + ".bias"]
+    xs = ctx.q(x)
     if not ctx.train:
         mean, var = P[key + ".running_mean"].detach(), P[key + ".running_var"].detach()
-        return (x - mean[None, :, None, None]) * torch.rsqrt(var + 1e-5)[None, :, None, None] * g[None, :, None, None] + b[None, :, None, None]
+        return (xs - mean[None, :, None, None]) * torch.rsqrt(var + 1e-5)[None, :, None, None] * g[None, :, None, None] + b[None, :, None, None]
     mean = x.mean((0, 2, 3))
     var = x.var((0, 2, 3), unbiased=False)
     n = x.numel() // x.shape[1]
     with torch.no_grad():
         ctx.bn_updates[key] = (0.9 * P[key + ".running_mean"] + 0.1 * mean,
                                0.9 * P[key + ".running_var"] + 0.1 * var * (n / max(n - 1, 1)))
-    return (x - mean[None, :, None, None]) * torch.rsqrt(var + 1e-5)[None, :, None, None] * g[None, :, None, None] + b[None, :, None, None]
+    return (xs - mean[None, :, None, None]) * torch.rsqrt(var + 1e-5)[None, :, None, None] * g[None, :, None, None] + b[None, :, None, None]
 
 
 def conv_bn(x, P, ckey, bkey, ctx, stride=1, relu=False):
@@ -70,7 +102,7 @@ def bottleneck(x, P, pre, ctx):
     y = batchnorm(conv(y, P, pre + ".conv3"), P, pre + ".bn3", ctx)
     res = x
     if pre + ".downsample.0.weight" in P:
-        res = batchnorm(conv(x, P, pre + ".downsample.0"), P, pre + ".downsample.1", ctx)
+        res = ctx.q(batchnorm(conv(x, P, pre + ".downsample.0"), P, pre + ".downsample.1", ctx))
     return ctx.q(torch.relu(y + res))
 
 
@@ -101,7 +133,7 @@ def exchange(xs, P, pre, ctx, n_out=None):
             if j == i:
                 t = xs[j]
             elif j > i:
-                t = batchnorm(conv(xs[j], P, f"{pre}.{i}.{j}.0"), P, f"{pre}.{i}.{j}.1", ctx)
+                t = ctx.q(batchnorm(conv(xs[j], P, f"{pre}.{i}.{j}.0"), P, f"{pre}.{i}.{j}.1", ctx))     # stored, then up-sampled inside the sum
                 t = upsample_bilinear(t, xs[i].shape[-2:])
             else:
                 t = xs[j]
@@ -210,6 +242,7 @@ def transition(ys, P, pre, n_cur, ctx):
 def backbone(x, P, ctx, pre="backbone"):
     """HRFormer or HRNet, decided by the keys present. Returns branch-0 feature (B,C0,H/4,W/4)."""
     is_former = any(".attn.qkv.weight" in k for k in P if k.startswith(pre))
+    x = ctx.q(x)                        # the HIP path converts the image to bf16 NHWC once
     x = conv_bn(x, P, pre + ".conv1", pre + ".bn1", ctx, stride=2, relu=True)
     x = conv_bn(x, P, pre + ".conv2", pre + ".bn2", ctx, stride=2, relu=True)
     for i in range(_count(P, pre + ".layer1")):

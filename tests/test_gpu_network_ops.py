@@ -153,7 +153,9 @@ def test_conv_bn_act_function(N, train, relu, res):
     P = {"c.weight": conv.weight.detach().clone().requires_grad_(True), "b.weight": bn.weight.detach().clone().requires_grad_(True),
          "b.bias": bn.bias.detach().clone().requires_grad_(True), "b.running_mean": bn.running_mean.clone(), "b.running_var": bn.running_var.clone(),
          "b.num_batches_tracked": torch.zeros((), dtype=torch.int64)}
-    ctx = onet.Ctx(train=train)
+    # reference = the oracle with the kernel's storage rounding emulated: the raw conv output is stored in bf16 and THAT is normalised
+    # (statistics from the fp32 accumulators), so the ReLU mask is the mask of the same numbers the kernel sees
+    ctx = onet.Ctx(train=train, q=onet.bf16_storage)
     xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
     y_ref = onet.batchnorm(onet.conv(xr, P, "c"), P, "b", ctx)
     if res:
@@ -165,21 +167,20 @@ def test_conv_bn_act_function(N, train, relu, res):
     with N.use_weights(m):
         xd, rd = nhwc(x).requires_grad_(True), nhwc(r).requires_grad_(True)
         y = N.conv_bn_act(xd, m.c, m.b, relu, rd if res else None, train)
-        assert err(nchw(y), y_ref.detach()) < 1e-2
+        assert err(nchw(y), y_ref.detach()) < 8e-3          # one bf16 store of an O(1) output: 2 ulp
         if not train:
             return
         y_ref.backward(gy)
         y.backward(nhwc(gy))
-        # with ReLU the mask is taken from the bf16-stored output: a handful of near-zero elements flip relative to fp32,
-        # each an O(1) change of its gradient -> looser norm-wise bound than the mask-free case
-        # (L2 for the ReLU cases: isolated flipped elements dominate the max-norm)
-        assert (err2 if relu else err)(nchw(xd.grad), xr.grad) < 3e-2
+        # r01 compared with the fp32 oracle and needed 3e-2 / L2 because ReLU masks taken from bf16-stored activations flip a few near-zero
+        # elements; against the storage-aware oracle the masks agree and the max-norm bar is 2e-2 again (the only extra rounding left is the
+        # bf16 store of draw, the BatchNorm input gradient)
+        rep = {"gx": err(nchw(xd.grad), xr.grad), "gw": err(C(m.c.weight.grad), P["c.weight"].grad),
+               "ggamma": err(C(m.b.weight.grad), P["b.weight"].grad), "gbeta": err(C(m.b.bias.grad), P["b.bias"].grad)}
         if res:
-            assert (err2 if relu else err)(nchw(rd.grad), rr.grad) < 3e-2
-        e = err2 if relu else err
-        assert e(C(m.c.weight.grad), P["c.weight"].grad) < 3e-2
-        assert e(C(m.b.weight.grad), P["b.weight"].grad) < 3e-2
-        assert e(C(m.b.bias.grad), P["b.bias"].grad) < 3e-2
+            rep["gres"] = err(nchw(rd.grad), rr.grad)
+        print("conv_bn_act vs storage-aware oracle", {k: round(v, 4) for k, v in rep.items()})
+        assert all(v < 2e-2 for v in rep.values()), rep
         onet.apply_bn_updates(P, ctx)
         assert err(C(m.b.running_mean), P["b.running_mean"]) < 5e-3
         assert err(C(m.b.running_var), P["b.running_var"]) < 5e-3

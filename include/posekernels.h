@@ -68,6 +68,21 @@ int pk_affine_coords(const float* coords, const float* center, const float* scal
                      float mul_x, float mul_y, const float* mask_maxvals, float threshold, void* stream);
                      /* out = mask * coords * (scale*mul) + center - scale/2 : transform_preds / train.py:328-336 */
 
+/* ---- f1: COCOEvaluator.update arrays (utils/metrics.py:84-106): records (B,K,3) = [x, y, score], instance_score (B) = mean of
+ * the strictly positive keypoint scores (0 if none) ----------------------------------------------------------------------- */
+int pk_pose_records(const float* keypoints, const float* scores, float* records, float* instance_score, int B, int K,
+                    void* stream);
+
+/* ---- f2: input pipeline (datasets/transforms.py:42-47,128-131,212-217; datasets/coco_dataset.py:156-163; inference.py:83-110):
+ * affine crop (OpenCV 8-bit warpAffine INTER_LINEAR / BORDER_CONSTANT 0 integer algorithm, see oracle/warp.py; parity unpinned vs cv2
+ * itself) + optional column mirror + optional BGR->RGB + ((v/255) - mean)/std, whole batch, one launch.  src_u8: device buffer holding the
+ * decoded (H,W,3) uint8 images; desc_table rows (72 bytes): { int64 src_offset; int32 H, W, flip, bgr; double minv[6] } with minv the
+ * INVERSE (destination->source) matrix in float64; mean3/std3 are HOST pointers (read before the launch returns).  Outputs (either may be
+ * NULL): fp32 NCHW (B,3,out_h,out_w) -- the reference's batch['img'] -- and bf16 NHWC with 8-channel pixels (B,out_h,out_w,8), the stem
+ * convolution's input layout (channels 3..7 zero).                                                                                 */
+int pk_affine_crop_normalize(const void* src_u8, const void* desc_table, int n_samples, int out_w, int out_h, float* out_nchw_f32,
+                             void* out_nhwc8_bf16, const float* mean3, const float* std3, void* stream);
+
 /* ---- D4: flip-test merge (models/pose_estimator.py:303-319): out = (a + swapLR(flipW(b)))/2 ------------- */
 int pk_flip_merge(const float* a, const float* b_flipped, const int32_t* partner, float* out,
                   int B, int K, int H, int W, void* stream);

@@ -440,3 +440,106 @@ extern "C" int pk_nms_pose(const float* preds, const float* maxvals, float* out,
     hipLaunchKernelGGL(k_nms_pose, dim3((B + 63) / 64), dim3(64), 0, (hipStream_t)stream, preds, maxvals, out, keep, B, K, distance_threshold);
     return pk_launch_status("pk_nms_pose");
 }
+
+// ================================================================================================ f1: evaluator records
+// COCOEvaluator.update (utils/metrics.py:84-106): per instance a (K,3) array [x, y, score] and the instance score = mean of the
+// strictly positive keypoint scores (0 when there is none).  One 64-lane wave per instance; the mean is an fp32 sum in keypoint
+// order divided by the count (numpy's float32 mean sums pairwise: equal to 1e-6 relative, stated in the test).
+__global__ void __launch_bounds__(64) k_pose_records(const float* __restrict__ kp, const float* __restrict__ sc, float* __restrict__ rec,
+                                                    float* __restrict__ inst, int K) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    for (int k = t; k < K; k += 64) {
+        rec[((size_t)b * K + k) * 3 + 0] = kp[((size_t)b * K + k) * 2 + 0];
+        rec[((size_t)b * K + k) * 3 + 1] = kp[((size_t)b * K + k) * 2 + 1];
+        rec[((size_t)b * K + k) * 3 + 2] = sc[(size_t)b * K + k];
+    }
+    if (t == 0) {
+        float s = 0.f;
+        int n = 0;
+        for (int k = 0; k < K; ++k) {
+            const float v = sc[(size_t)b * K + k];
+            if (v > 0.f) {
+                s += v;
+                ++n;
+            }
+        }
+        inst[b] = n > 0 ? s / (float)n : 0.f;
+    }
+}
+extern "C" int pk_pose_records(const float* keypoints, const float* scores, float* records, float* instance_score, int B, int K,
+                               void* stream) {
+    PK_REQUIRE(keypoints && scores && records && instance_score && B > 0 && K > 0, "pk_pose_records: bad argument");
+    hipLaunchKernelGGL(k_pose_records, dim3(B), dim3(64), 0, (hipStream_t)stream, keypoints, scores, records, instance_score, K);
+    return pk_launch_status("pk_pose_records");
+}
+
+// ================================================================================================ f2: input pipeline
+// TopdownAffine(+rotation) image crop + RandomFlip + ToTensor/normalise of the reference's data pipeline (datasets/transforms.py:42-47,
+// 128-131, 212-217; datasets/coco_dataset.py:156-163; inference.py:93-110) for a whole batch in ONE launch, straight from the decoded
+// uint8 images to the network input.  The warp follows OpenCV's 8-bit `warpAffine(INTER_LINEAR, BORDER_CONSTANT 0)` integer algorithm as
+// restated in oracle/warp.py (coordinates in 10-bit fixed point rounded half-to-even, 5 bits of sub-pixel position, weights that sum to
+// 2^15, (sum + 2^14) >> 15) -- integer work, bit-exact against that restatement; cv2 itself is not in the image (parity unpinned vs cv2).
+// Normalisation is the reference's fp32 expression ((v / 255) - mean) / std with correctly rounded divisions.
+struct CropDesc {
+    int64_t src_offset;      // byte offset of this sample's (H, W, 3) uint8 image inside the source buffer
+    int32_t H, W;
+    int32_t flip;            // mirror the source columns (RandomFlip flips the image before the warp)
+    int32_t bgr;             // source is BGR (cv2.imread / inference.py:83): swap to RGB
+    double minv[6];          // inverse (destination -> source) affine matrix, float64 as OpenCV holds it
+};
+__global__ void __launch_bounds__(256) k_affine_crop(const unsigned char* __restrict__ src, const CropDesc* __restrict__ desc, int out_w, int out_h,
+                                                     float* __restrict__ out_nchw, uint16_t* __restrict__ out_nhwc8, float m0, float m1, float m2,
+                                                     float s0, float s1, float s2) {
+    const CropDesc d = desc[blockIdx.y];
+    const int pix = blockIdx.x * 256 + threadIdx.x;
+    if (pix >= out_w * out_h) return;
+    const int y = pix / out_w, x = pix - y * out_w;
+    auto sat = [](double v) { return (long long)max(-2147483648.0, min(2147483647.0, rint(v))); };
+    const long long adelta = sat(__dmul_rn(__dmul_rn(d.minv[0], (double)x), 1024.0)), bdelta = sat(__dmul_rn(__dmul_rn(d.minv[3], (double)x), 1024.0));
+    const long long X0 = sat(__dmul_rn(__dadd_rn(__dmul_rn(d.minv[1], (double)y), d.minv[2]), 1024.0)) + 16;
+    const long long Y0 = sat(__dmul_rn(__dadd_rn(__dmul_rn(d.minv[4], (double)y), d.minv[5]), 1024.0)) + 16;
+    const long long X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+    const long long sx = max(-32768LL, min(32767LL, X >> 5)), sy = max(-32768LL, min(32767LL, Y >> 5));
+    const int a = (int)(X & 31), b = (int)(Y & 31);
+    const int w4[4] = {(32 - a) * (32 - b) * 32, a * (32 - b) * 32, (32 - a) * b * 32, a * b * 32};
+    int acc[3] = {0, 0, 0};
+    const unsigned char* img = src + d.src_offset;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const long long xx = sx + (t & 1), yy = sy + (t >> 1);
+        if (xx < 0 || xx >= d.W || yy < 0 || yy >= d.H) continue;
+        const long long xs = d.flip ? d.W - 1 - xx : xx;
+        const unsigned char* p = img + (yy * d.W + xs) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[c] += w4[t] * (int)p[d.bgr ? 2 - c : c];
+    }
+    const float mean[3] = {m0, m1, m2}, sd[3] = {s0, s1, s2};
+    float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int u = min(255, max(0, (acc[c] + (1 << 14)) >> 15));
+        v[c] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)u, 255.0f), mean[c]), sd[c]);
+    }
+    const size_t plane = (size_t)out_w * out_h;
+    if (out_nchw) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) out_nchw[((size_t)blockIdx.y * 3 + c) * plane + pix] = v[c];
+    }
+    if (out_nhwc8) {
+        uint4 o;
+        o.x = pack_bf16x2(v[0], v[1]);
+        o.y = pack_bf16x2(v[2], 0.f);
+        o.z = o.w = 0u;
+        *reinterpret_cast<uint4*>(out_nhwc8 + ((size_t)blockIdx.y * plane + pix) * 8) = o;
+    }
+}
+extern "C" int pk_affine_crop_normalize(const void* src_u8, const void* desc_table, int n_samples, int out_w, int out_h, float* out_nchw_f32,
+                                        void* out_nhwc8_bf16, const float* mean3, const float* std3, void* stream) {
+    PK_REQUIRE(src_u8 && desc_table && n_samples > 0 && out_w > 0 && out_h > 0 && (out_nchw_f32 || out_nhwc8_bf16) && mean3 && std3,
+               "pk_affine_crop_normalize: bad argument");
+    PK_REQUIRE(!out_nhwc8_bf16 || (((uintptr_t)out_nhwc8_bf16) & 15) == 0, "pk_affine_crop_normalize: 16-byte alignment of the NHWC output");
+    hipLaunchKernelGGL(k_affine_crop, dim3((out_w * out_h + 255) / 256, n_samples), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)src_u8,
+                       (const CropDesc*)desc_table, out_w, out_h, out_nchw_f32, (uint16_t*)out_nhwc8_bf16, mean3[0], mean3[1], mean3[2], std3[0],
+                       std3[1], std3[2]);
+    return pk_launch_status("pk_affine_crop_normalize");
+}

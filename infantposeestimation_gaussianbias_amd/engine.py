@@ -363,7 +363,9 @@ class Trainer:
     def _fwd_bwd(self, batch):
         nnops._PENDING.clear()         # reductions registered by a step that did not finish (exception) must not leak into this one
         self.opt.zero_grad()
-        out = self.model(batch["img"], batch["target"], batch["target_weight"], gt_keypoints=batch.get("keypoints"),
+        # the device input pipeline hands over the stem's own layout (bf16 NHWC, 8-channel pixels): no conversion launch
+        x = batch["img_nhwc8"] if batch.get("img_nhwc8") is not None else batch["img"]
+        out = self.model(x, batch["target"], batch["target_weight"], gt_keypoints=batch.get("keypoints"),
                          input_size=self.cfg.data.input_size)
         out["loss"].backward()
         nnops.finalize_deferred()      # ONE launch: all postponed slab reductions of parameter gradients
@@ -387,7 +389,8 @@ class Trainer:
         return (self.comm.world > 1 and dist.get_backend(self.comm.group) == "nccl" and os.environ.get("POSE_GRAPH_COMM", "1") != "0")
 
     def _capture(self, batch):
-        keys = [k for k in ("img", "target", "target_weight", "keypoints") if batch.get(k) is not None]
+        keys = [k for k in ("img_nhwc8" if batch.get("img_nhwc8") is not None else "img", "target", "target_weight", "keypoints")
+                if batch.get(k) is not None]
         self._static = {k: batch[k].clone() for k in keys}
         world = self.comm.world
         attempts = [True, False] if self._comm_capturable() else [world == 1]

@@ -116,6 +116,16 @@ def affine_coords(coords, center, scale, mul_x, mul_y, mask_maxvals=None, thresh
     return out
 
 
+def pose_records(keypoints, scores):
+    """(B,K,2), (B,K) -> records (B,K,3) = [x, y, score], instance score (B,) = mean of the positive scores (COCOEvaluator.update)."""
+    kp, sc = _chk(keypoints, name="keypoints"), _chk(scores, name="scores")
+    B, K = sc.shape
+    rec = torch.empty(B, K, 3, dtype=F32, device=kp.device)
+    inst = torch.empty(B, dtype=F32, device=kp.device)
+    call("pk_pose_records", kp, sc, rec, inst, B, K, stream_ptr())
+    return rec, inst
+
+
 def flip_merge(hm, hm_from_flipped, partner):
     a, b = _chk(hm), _chk(hm_from_flipped)
     B, K, H, W = a.shape

@@ -297,7 +297,10 @@ def _wc():
 
 # ================================================================================================ helpers
 def to_features(x_nchw_f32, cpad=8):
-    """(B,Cin,H,W) fp32 NCHW -> (B,H,W,cpad) bf16 NHWC, channels >= Cin zero (16-byte pixels for the stem conv)."""
+    """(B,Cin,H,W) fp32 NCHW -> (B,H,W,cpad) bf16 NHWC, channels >= Cin zero (16-byte pixels for the stem conv).
+    A bf16 (B,H,W,cpad) tensor is taken as already packed (datasets.transforms.DeviceCropper writes the stem's layout directly)."""
+    if x_nchw_f32.dtype == BF16 and x_nchw_f32.dim() == 4 and x_nchw_f32.shape[-1] == cpad:
+        return x_nchw_f32.contiguous()
     x = x_nchw_f32.float().contiguous()
     B, Cin, H, W = x.shape
     y = _e((B, H, W, max(cpad, _up8(Cin))), BF16, x.device)

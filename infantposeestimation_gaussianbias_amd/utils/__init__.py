@@ -1,5 +1,5 @@
 """Utils module."""
-from .metrics import AverageMeter, MetricLogger
+from .metrics import AverageMeter, COCOEvaluator, MetricLogger
 from . import postprocess
 
-__all__ = ['AverageMeter', 'MetricLogger', 'postprocess']
+__all__ = ['AverageMeter', 'COCOEvaluator', 'MetricLogger', 'postprocess']

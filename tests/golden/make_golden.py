@@ -622,7 +622,109 @@ def cap_schedule():
     return meta
 
 
+# ----------------------------------------------------------------------------- round 2 additions: f4, cfg 4 training, f1
+def cap_extra():
+    """optimizer-state interchange (train.py:55-128,339-368), an HRNet-W32 heatmap-head train step (BASELINE cfg 4) and the
+    COCOEvaluator bookkeeping (utils/metrics.py:61-106,107-270)."""
+    import train as rt
+    import models
+    from configs.config import get_config
+    from models import hrformer as hf
+    meta, out = {}, {}
+    # ---- f4: the reference's build_optimizer / build_scheduler on a small two-branch HRFormer module, three steps
+    cfg = get_config()
+    mod = hf.HRFormerModule(2, "HRFORMERBLOCK", [1, 1], [16, 32], [1, 2], [4, 4], [7, 7], 0.0)
+    spec = load_recipe(mod, salt=21)
+    mod.train()
+    opt = rt.build_optimizer(mod, cfg)
+    sched = rt.build_scheduler(opt, cfg, num_iters_per_epoch=2)
+    xs = [T(synth_input("opt_x0", (2, 16, 8, 6))), T(synth_input("opt_x1", (2, 32, 4, 3)))]
+    gys = None
+    names = [k for k, _ in mod.named_parameters()]
+    for step in range(3):
+        opt.zero_grad()
+        ys = mod([x.clone() for x in xs])
+        if gys is None:
+            gys = [T(synth_input(f"opt_gy{i}", y.shape)) for i, y in enumerate(ys)]
+        loss = sum((y * g).sum() for y, g in zip(ys, gys))
+        loss.backward()
+        if step == 2:
+            for k, p in mod.named_parameters():
+                out["optim_grad3." + k] = N(p.grad).copy()
+        opt.step()
+        sched.step()
+        if step == 1:           # state after two steps = what a checkpoint written there holds (train.py:351-357)
+            sd = opt.state_dict()
+            for idx, st in sd["state"].items():
+                out[f"optim_state.{idx}.step"] = np.asarray(float(st["step"]))
+                # (copies: the optimiser keeps updating these tensors in place in the third step)
+                out[f"optim_state.{idx}.exp_avg"], out[f"optim_state.{idx}.exp_avg_sq"] = N(st["exp_avg"]).copy(), N(st["exp_avg_sq"]).copy()
+            meta["optim_param_groups"] = [{k: (list(v) if isinstance(v, (list, tuple)) else v) for k, v in g.items()} for g in sd["param_groups"]]
+            meta["optim_sched"] = {k: v for k, v in sched.state_dict().items() if k != "lr_lambdas"}
+            for k, p in mod.named_parameters():
+                out["optim_w2." + k] = N(p).copy()
+            for k, b in mod.named_buffers():
+                if b.is_floating_point():
+                    out["optim_b2." + k] = N(b).copy()
+    for k, p in mod.named_parameters():
+        out["optim_w3." + k] = N(p)
+    meta["optim_spec"], meta["optim_names"] = spec, names
+    meta["optim_lr_after3"] = [g["lr"] for g in opt.param_groups]
+    # ---- cfg 4: HRNet-W32 + HeatmapHead + KeypointMSELoss train step at fixture size (B=2, 128x96)
+    w32 = models.PoseEstimator("hrnet_w32", 17, False, "heatmap", True)
+    load_recipe(w32, salt=42)
+    w32.train()
+    hm, off, var, tgt, w, gt = synth_loss_inputs("w32_train", 2, 17, 32, 24, 96, 128, True)
+    x = T(synth_input("w32_train", (2, 3, 128, 96)))
+    o = w32(x, T(tgt), T(w))
+    w32.zero_grad(set_to_none=True)
+    o["loss"].backward()
+    out["w32_train_loss"], out["w32_train_tgt"], out["w32_train_w"], out["w32_train_hm"] = np.asarray(float(o["loss"])), tgt, w, N(o["heatmaps"])
+    gn = {k: float(p.grad.norm()) if p.grad is not None else -1.0 for k, p in w32.named_parameters()}
+    meta["w32_train_gradnorm"] = gn
+    meta["w32_train_nograd"] = [k for k, v in gn.items() if v < 0]
+    for k in ("backbone.conv1.weight", "head.final_layer.weight", "head.final_layer.bias", "backbone.stage3.1.branches.1.2.conv2.weight",
+              "backbone.stage4.2.fuse_layers.0.3.0.weight"):
+        out["w32_train_g." + k] = N(dict(w32.named_parameters())[k].grad)
+    # ---- f1: COCOEvaluator.update / compute_oks / manual evaluation on synthetic predictions
+    from utils.metrics import COCOEvaluator
+    rng = np.random.default_rng(5)
+    B, K = 6, 17
+    pk = (rng.uniform(0, 400, (B, K, 2))).astype(np.float32)
+    ps = rng.uniform(-0.2, 1.0, (B, K)).astype(np.float32)
+    ps[2] = -0.5                                   # an instance without any positive score
+    ps[3, :5] = 0.0
+    ids, anns = [11, 11, 12, 13, 13, 13], [1, 2, 3, 4, 5, 6]
+    centers, scales = rng.uniform(50, 300, (B, 2)).astype(np.float32), rng.uniform(80, 200, (B, 2)).astype(np.float32)
+    areas = rng.uniform(2000, 30000, B).astype(np.float32)
+    bboxes = rng.uniform(0, 300, (B, 4)).astype(np.float32)
+    ev = COCOEvaluator(ann_file=None, num_keypoints=K)
+    ev.update(pk, ps, ids, anns, centers, scales, areas, bboxes)
+    gts = []
+    for i in range(B):
+        kp3 = np.zeros((K, 3), np.float32)
+        kp3[:, :2] = pk[i] + rng.normal(0, 6.0 if i % 2 else 1.5, (K, 2))
+        kp3[:, 2] = rng.choice([0, 1, 2], K, p=[0.2, 0.3, 0.5])
+        gts.append({"image_id": ids[i], "keypoints": kp3.flatten().tolist(), "area": float(areas[i])})
+    metrics = ev.evaluate(gt_annotations=gts)
+    out.update(eval_pk=pk, eval_ps=ps, eval_centers=centers, eval_scales=scales, eval_areas=areas, eval_bboxes=bboxes)
+    out["eval_oks"] = np.array([ev.compute_oks(pk[i], np.asarray(gts[i]["keypoints"]).reshape(-1, 3)[:, :2],
+                                               np.asarray(gts[i]["keypoints"]).reshape(-1, 3)[:, 2], gts[i]["area"]) for i in range(B)])
+    meta["eval"] = {"image_ids": ids, "ann_ids": anns, "predictions": ev.predictions, "gts": gts,
+                    "metrics": {k: float(v) for k, v in metrics.items()}}
+    save("extra_r02.npz", **out)
+    return meta
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":      # round-2 fixtures only (the others stay byte-identical)
+        with open(os.path.join(HERE, "meta.json")) as f:
+            meta = json.load(f)
+        meta["extra"] = cap_extra()
+        with open(os.path.join(HERE, "meta.json"), "w") as f:
+            json.dump(meta, f, separators=(",", ":"))
+        print("done (extra)")
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "video":      # add the video post-processing fixtures only
         cap_video()
         print("done (video)")
@@ -647,6 +749,7 @@ def main():
     meta["schedule"] = cap_schedule()
     meta["base"] = cap_base()
     cap_video()
+    meta["extra"] = cap_extra()
     meta["torch"] = torch.__version__
     with open(os.path.join(HERE, "meta.json"), "w") as f:
         json.dump(meta, f, separators=(",", ":"))

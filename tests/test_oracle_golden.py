@@ -414,3 +414,19 @@ def test_optimizer_groups_and_schedule(golden):
     assert s["wd"] == [0.01, 0.0]
     for it, f in zip(s["lr_iters"], s["lr_factor"]):
         assert math.isclose(oopt.lr_factor(it, s["iters_per_epoch"]), f, rel_tol=1e-12), it
+
+
+def test_evaluator_bookkeeping_vs_reference(golden):
+    """oracle/evalglue.py against the reference's own COCOEvaluator (update records, compute_oks, greedy-matching precision)."""
+    from oracle import evalglue as og
+    z, meta = golden("extra_r02.npz"), golden("meta.json")["extra"]["eval"]
+    recs = og.records(z["eval_pk"], z["eval_ps"], meta["image_ids"], meta["ann_ids"], z["eval_areas"], z["eval_bboxes"])
+    assert len(recs) == len(meta["predictions"])
+    for a, b in zip(recs, meta["predictions"]):
+        assert a["image_id"] == b["image_id"] and a["ann_id"] == b["ann_id"] and a["keypoints"] == b["keypoints"] and a["bbox"] == b["bbox"]
+        assert a["score"] == b["score"] and a["area"] == b["area"]
+    for i, g in enumerate(meta["gts"]):
+        gk = np.asarray(g["keypoints"]).reshape(-1, 3)
+        assert abs(og.oks(z["eval_pk"][i].astype(np.float64), gk[:, :2], gk[:, 2], g["area"]) - float(z["eval_oks"][i])) < 1e-12
+    m = og.precision_metrics(meta["predictions"], meta["gts"])
+    assert all(abs(m[k] - meta["metrics"][k]) < 1e-12 for k in ("AP", "AP50", "AP75")), (m, meta["metrics"])

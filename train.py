@@ -97,10 +97,18 @@ def main(args):
         trainer.sched.load_state_dict(ckpt["scheduler_state_dict"])
         start_epoch, best_ap = ckpt["epoch"] + 1, ckpt.get("metrics", {}).get("AP", 0.0)
         logger.info(f"Resumed from epoch {start_epoch}")
+    val_loader = None
     for epoch in range(start_epoch, cfg.train.max_epochs):
         loss = train_one_epoch(trainer, loader, epoch, cfg, logger, rank)
         if rank == 0 and ((epoch + 1) % cfg.train.val_interval == 0 or epoch == cfg.train.max_epochs - 1):
-            save_checkpoint(model, trainer, epoch, {"loss": loss, "AP": best_ap}, out_dir, is_best=False)
+            # validation inside the training loop (train.py:231-325, 437-452 of the reference): AP decides `best.pth`
+            from validate import validate
+            val_loader = val_loader or build_dataloader(cfg, is_train=False)
+            metrics, _ = validate(model, val_loader, torch.device("cuda", local), cfg, logger, flip_test=False)
+            model.train()
+            is_best = metrics["AP"] > best_ap
+            best_ap = max(best_ap, metrics["AP"])
+            save_checkpoint(model, trainer, epoch, dict({k: float(v) for k, v in metrics.items()}, train_loss=float(loss)), out_dir, is_best=is_best)
     if world > 1:
         dist.destroy_process_group()
 

@@ -3,8 +3,9 @@
 
 Flip-test inference + decode run entirely on the GPU (`PoseEstimator.inference`: two forwards, one flip-merge kernel, one
 decode kernel); the heat-px -> image transform of validate.py:100-117 is one kernel (`heatmap_to_image_coords`) instead of a
-Python B x K loop.  COCO AP needs pycocotools + annotation files on the machine (third-party, outside the hot path): when
-they are missing the script reports the loss and the decoded keypoints only.
+Python B x K loop; `COCOEvaluator.update` receives device tensors.  COCO AP needs pycocotools + annotation files on the machine
+(third-party, outside the hot path): when they are missing, AP is the reference's own OKS matching (utils/metrics.py:206-270) against the
+loader's ground truth.
 """
 import argparse
 import logging
@@ -22,34 +23,52 @@ from infantposeestimation_gaussianbias_amd.utils import AverageMeter  # noqa: E4
 from infantposeestimation_gaussianbias_amd.utils.postprocess import heatmap_to_image_coords  # noqa: E402
 
 
-@torch.no_grad()
-def validate(model, loader, device, cfg, logger, flip_test=True):
-    model.eval()
-    loss_meter = AverageMeter("Loss", ":.4f")
-    flip_pairs = cfg.data.flip_pairs if flip_test else None
-    results = []
-    for i, batch in enumerate(loader):
-        imgs = batch["img"].to(device)
-        if flip_test:
-            kp, sc = model.inference(imgs, flip=True, flip_pairs=flip_pairs)
-        else:
-            kp, sc = model.inference(imgs, flip=False)
-        out = model(imgs, batch["target"].to(device), batch["target_weight"].to(device),
-                    gt_keypoints=batch["keypoints"].to(device) if batch.get("keypoints") is not None else None,
-                    input_size=cfg.data.input_size)
-        loss_meter.update(float(out["loss"]), imgs.size(0))
-        meta = batch["meta"]
-        img_kp = heatmap_to_image_coords(kp, meta["center"].to(device), meta["scale"].to(device), cfg.data.input_size, cfg.data.heatmap_size)
-        results.append((img_kp.cpu(), sc.cpu(), meta["image_id"]))
-        if i % 50 == 0:
-            logger.info(f"  [{i}/{len(loader)}] Loss: {loss_meter.avg:.4f}")
-    metrics = {"loss": loss_meter.avg}
+def _coco_available(cfg):
+    ann = os.path.join(cfg.data.data_root, cfg.data.val_ann)
     try:
         import pycocotools  # noqa: F401
-        logger.info("pycocotools present: feed `results` to COCOeval for AP (annotation file required)")
     except ImportError:
-        logger.warning("pycocotools not installed: AP not computed (third-party, outside the hot path)")
-    return metrics, results
+        return None
+    return ann if os.path.isfile(ann) else None
+
+
+@torch.no_grad()
+def validate(model, loader, device, cfg, logger, flip_test=True):
+    """train.py:231-325 == validate.py:39-140 of the reference: loss + decode + image-space transform + COCOEvaluator.update per batch,
+    then AP.  Decode, flip merge, the heat-px -> image transform and the evaluator's record arrays are kernels (no B x K Python loops, one
+    device->host copy per batch).  AP comes from pycocotools when it and the annotation file exist; otherwise from the reference's own
+    OKS matching against the batch's ground truth mapped to image space (synthetic loaders carry no annotation file)."""
+    from infantposeestimation_gaussianbias_amd.utils import COCOEvaluator
+    model.eval()
+    loss_meter = AverageMeter("Loss", ":.4f")
+    ann = _coco_available(cfg)
+    evaluator = COCOEvaluator(ann_file=ann, num_keypoints=cfg.data.num_keypoints)
+    flip_pairs = cfg.data.flip_pairs if flip_test else None
+    gts = []
+    for i, batch in enumerate(loader):
+        imgs = batch["img"].to(device)
+        kp, sc = model.inference(imgs, flip=bool(flip_test and flip_pairs), flip_pairs=flip_pairs)
+        gt_kp = batch["keypoints"].to(device) if batch.get("keypoints") is not None else None
+        out = model(imgs, batch["target"].to(device), batch["target_weight"].to(device), gt_keypoints=gt_kp, input_size=cfg.data.input_size)
+        loss_meter.update(float(out["loss"]), imgs.size(0))
+        meta = batch["meta"]
+        center, scale = meta["center"].to(device).float(), meta["scale"].to(device).float()
+        img_kp = heatmap_to_image_coords(kp, center, scale, cfg.data.input_size, cfg.data.heatmap_size)
+        evaluator.update(img_kp, sc, meta["image_id"], meta["ann_id"], center, scale, meta["area"], meta["bbox"])
+        if ann is None and gt_kp is not None:
+            # ground truth in image space: the same inverse crop transform, applied to the input-pixel keypoints (heatmap size == input size)
+            gimg = heatmap_to_image_coords(gt_kp.float(), center, scale, cfg.data.input_size, cfg.data.input_size).cpu().numpy()
+            vis = batch["keypoints_visible"].cpu().numpy()
+            for b in range(gimg.shape[0]):
+                k3 = [[float(gimg[b, k, 0]), float(gimg[b, k, 1]), float(vis[b, k])] for k in range(gimg.shape[1])]
+                gts.append({"image_id": int(meta["image_id"][b]), "keypoints": [v for row in k3 for v in row], "area": float(meta["area"][b])})
+        if i % 50 == 0:
+            logger.info(f"  [{i}/{len(loader)}] Loss: {loss_meter.avg:.4f}")
+    metrics = dict(evaluator.evaluate(gt_annotations=None if ann else gts))
+    metrics["loss"] = loss_meter.avg
+    logger.info(f"Validation Loss: {loss_meter.avg:.4f}  AP: {metrics['AP']:.4f}  AP50: {metrics['AP50']:.4f}  AP75: {metrics['AP75']:.4f}"
+                + ("" if ann else "  (reference OKS matching against the loader's ground truth: no pycocotools / annotation file)"))
+    return metrics, evaluator.predictions
 
 
 def main(args):

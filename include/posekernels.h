@@ -97,17 +97,18 @@ int pk_nms_pose(const float* preds, const float* maxvals, float* out, uint8_t* k
 
 /* ---- L1/L2: FusionPoseLoss.forward (models/fusion_head.py:745-806 with :405-559, :637-743) ---------------
  * stats: workspace of B*K*PK_LOSS_STAT floats + B*16*4 floats + 16 floats (see PK_LOSS_WS_FLOATS);
- * losses: 7 floats (heatmap, offset, peak, variance, overlap, shape, total — already multiplied by lambdas). */
+ * losses: 7 floats (heatmap, offset, peak, variance, overlap, shape, total — already multiplied by lambdas).
+ * lambdas7: device array of 7 floats = the six term weights + the overlap threshold (GaussianDistributionConstraint, default 0.5). */
 #define PK_LOSS_STAT 24
 #define PK_LOSS_WS_FLOATS(B, K) ((B) * (K) * PK_LOSS_STAT + (B) * 16 * 4 + 16)
 int pk_fusion_loss_fwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
                        const float* weight, const float* gt_keypoints, float* ws, float* losses,
                        int B, int K, int H, int W, float in_w, float in_h, float sigma_t,
-                       const float* lambdas6, void* stream);
+                       const float* lambdas7, int use_target_weight /* 0: heatmap/offset/peak terms are plain (B,K) means */, void* stream);
 int pk_fusion_loss_bwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
                        const float* weight, const float* ws, const float* grad_total /*device scalar or NULL=1*/,
                        float* d_heatmaps, float* d_offsets, float* d_variances,
-                       int B, int K, int H, int W, float sigma_t, const float* lambdas6, void* stream);
+                       int B, int K, int H, int W, float sigma_t, const float* lambdas7, void* stream);
 
 /* ---- L3/L4: KeypointMSELoss (models/pose_estimator.py:102-143) and models/losses.py per-pixel losses ------
  * kind 0: mean(((p-t)*w)^2)  [KeypointMSELoss]; 1: mean(w*(p-t)^2) [FusedPoseLoss mse];
@@ -189,6 +190,8 @@ int pk_bn_finalize(const float* stats_partial, int tiles, int C, int count, cons
 int pk_bn_act(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
               int relu, void* stream);                       /* y = relu?(x*scale + shift (+ residual)) */
 int pk_bn_bwd_blocks(int64_t rows);                          /* partial needs blocks*2*C floats */
+/* pk_bn_bwd `relu`: bit 0 = the forward applied ReLU (mask from y_act); bit 1 = eval-mode BatchNorm (save_mean / save_rstd hold the
+ * running statistics, which are constants: dx = gamma * rstd * g, no batch-mean terms; dgamma / dbeta as in training).           */
 int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* save_mean, const float* save_rstd,
               const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
               int64_t rows, int C, int relu, void* stream);

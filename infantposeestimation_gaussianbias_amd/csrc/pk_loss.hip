@@ -12,7 +12,7 @@ __constant__ int c_skel[16][2] = {{0, 1}, {0, 2}, {1, 3}, {2, 4}, {5, 6}, {5, 7}
 enum { ST_M, ST_Z, ST_CX, ST_CY, ST_MSE, ST_ENT, ST_UBAR, ST_R, ST_SPREAD, ST_SIG, ST_MEANVAR, ST_SSUM, ST_OX, ST_OY,
        ST_DOXX, ST_DOXY, ST_DOYX, ST_DOYY, ST_QX, ST_QY, ST_QSUM, ST_GX, ST_GY, ST_W };
 // globals (16 floats after the pair block)
-enum { GL_S, GL_DEN, GL_TENT };
+enum { GL_S, GL_DEN, GL_TENT, GL_S3, GL_UTW };   // S3 / UTW: normaliser of the heatmap / offset / peak terms and the use_target_weight flag
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
 
@@ -110,19 +110,22 @@ __device__ __forceinline__ float smooth_l1(float e) { const float a = fabsf(e); 
 
 __global__ void __launch_bounds__(256) k_floss_final(float* __restrict__ stats, float* __restrict__ pairs, float* __restrict__ glob,
                                                      float* __restrict__ losses, int B, int K, float sigma_t,
-                                                     const float* __restrict__ lam) {
+                                                     const float* __restrict__ lam, int utw) {
     __shared__ float red[16];
     float sw = 0.f, a_hm = 0.f, a_off = 0.f, a_pk = 0.f, a_var = 0.f, a_sh = 0.f;
     const float tent = logf(2.f * 3.14159265358979323846f * 2.71828182845904523536f * sigma_t * sigma_t);
     for (int m = threadIdx.x; m < B * K; m += blockDim.x) {
         const float* s = stats + (size_t)m * PK_LOSS_STAT;
         const float w = s[ST_W];
+        // use_target_weight=False (fusion_head.py:653-657,708-712,739-743): the heatmap / offset / peak terms are plain means over
+        // (B, K); the Gaussian-constraint terms below are weighted either way (fusion_head.py:478-480,523-527,555-557)
+        const float w3 = utw ? w : 1.f;
         sw += w;
-        a_hm += w * s[ST_MSE];
+        a_hm += w3 * s[ST_MSE];
         const float ex = s[ST_OX] - (s[ST_GX] - s[ST_CX]), ey = s[ST_OY] - (s[ST_GY] - s[ST_CY]);
-        a_off += w * 0.5f * (smooth_l1(ex) + smooth_l1(ey));
+        a_off += w3 * 0.5f * (smooth_l1(ex) + smooth_l1(ey));
         const float px = s[ST_CX] - s[ST_GX], py = s[ST_CY] - s[ST_GY];
-        a_pk += w * (px * px + py * py);
+        a_pk += w3 * (px * px + py * py);
         const float ds = s[ST_SIG] - sigma_t, dv = s[ST_MEANVAR] - sigma_t;
         a_var += w * (ds * ds + dv * dv);
         const float de = s[ST_ENT] - tent;
@@ -138,7 +141,7 @@ __global__ void __launch_bounds__(256) k_floss_final(float* __restrict__ stats, 
             mn = fminf(si[ST_SSUM], sj[ST_SSUM]) + EPS8;
             r = pairs[(size_t)q * 4] / mn;
             v = si[ST_W] * sj[ST_W];
-            num += fmaxf(r - 0.5f, 0.f) * v;
+            num += fmaxf(r - lam[6], 0.f) * v;          // lam[6] = overlap threshold (fusion_head.py:404,521)
             den += v;
         }
         pairs[(size_t)q * 4 + 1] = mn;
@@ -148,11 +151,13 @@ __global__ void __launch_bounds__(256) k_floss_final(float* __restrict__ stats, 
     sw = block_sum(sw, red); a_hm = block_sum(a_hm, red); a_off = block_sum(a_off, red); a_pk = block_sum(a_pk, red);
     a_var = block_sum(a_var, red); a_sh = block_sum(a_sh, red); num = block_sum(num, red); den = block_sum(den, red);
     if (threadIdx.x != 0) return;
-    const float S = sw + EPS8;
+    const float S = sw + EPS8, S3 = utw ? S : (float)(B * K);
     glob[GL_S] = S;
     glob[GL_DEN] = den + EPS8;
     glob[GL_TENT] = tent;
-    float l[6] = {lam[0] * a_hm / S, lam[1] * a_off / S, lam[2] * a_pk / S, lam[3] * a_var / S, lam[4] * (num / (den + EPS8)),
+    glob[GL_S3] = S3;
+    glob[GL_UTW] = (float)utw;
+    float l[6] = {lam[0] * a_hm / S3, lam[1] * a_off / S3, lam[2] * a_pk / S3, lam[3] * a_var / S, lam[4] * (num / (den + EPS8)),
                   lam[5] * a_sh / S};
     float tot = 0.f;
     for (int q = 0; q < 6; ++q) {
@@ -164,7 +169,7 @@ __global__ void __launch_bounds__(256) k_floss_final(float* __restrict__ stats, 
 
 extern "C" int pk_fusion_loss_fwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
                                   const float* weight, const float* gt_keypoints, float* ws, float* losses, int B, int K, int H,
-                                  int W, float in_w, float in_h, float sigma_t, const float* lambdas6, void* stream) {
+                                  int W, float in_w, float in_h, float sigma_t, const float* lambdas6, int use_target_weight, void* stream) {
     PK_REQUIRE(heatmaps && offsets && variances && target && weight && gt_keypoints && ws && losses && lambdas6,
                "pk_fusion_loss_fwd: null pointer");
     PK_REQUIRE(B > 0 && K > 0 && H > 1 && W > 1 && in_w > 0 && in_h > 0 && sigma_t > 0, "pk_fusion_loss_fwd: bad shape B=%d K=%d H=%d W=%d",
@@ -176,7 +181,7 @@ extern "C" int pk_fusion_loss_fwd(const float* heatmaps, const float* offsets, c
     hipLaunchKernelGGL(k_floss_map, dim3(B * K), dim3(256), 0, st, heatmaps, offsets, variances, target, weight, gt_keypoints, stats,
                        H, W, in_w, in_h);
     hipLaunchKernelGGL(k_floss_pair, dim3(B * 16), dim3(256), 0, st, heatmaps, pairs, K, H * W);
-    hipLaunchKernelGGL(k_floss_final, dim3(1), dim3(256), 0, st, stats, pairs, glob, losses, B, K, sigma_t, lambdas6);
+    hipLaunchKernelGGL(k_floss_final, dim3(1), dim3(256), 0, st, stats, pairs, glob, losses, B, K, sigma_t, lambdas6, use_target_weight ? 1 : 0);
     return pk_launch_status("pk_fusion_loss_fwd");
 }
 
@@ -191,18 +196,18 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
     const float* glob = pairs + (size_t)B * 16 * 4;
     const float G = gtot ? gtot[0] : 1.f;
     const float S = glob[GL_S], den = glob[GL_DEN], tent = glob[GL_TENT];
-    const float w = s[ST_W], wS = G * w / S;
+    const float w = s[ST_W], wS = G * w / S, w3S = G * (glob[GL_UTW] != 0.f ? w : 1.f) / glob[GL_S3];
     const float cx = s[ST_CX], cy = s[ST_CY], mx = s[ST_M], zinv = 1.f / s[ST_Z];
     // d total / d c
     const float ex = s[ST_OX] - (s[ST_GX] - cx), ey = s[ST_OY] - (s[ST_GY] - cy);
     const float sgx = fabsf(ex) < 1.f ? ex : (ex > 0.f ? 1.f : -1.f), sgy = fabsf(ey) < 1.f ? ey : (ey > 0.f ? 1.f : -1.f);
-    const float koff = lam[1] * wS * 0.5f;
+    const float koff = lam[1] * w3S * 0.5f;
     const float kvar = lam[3] * wS * 2.f * (s[ST_SIG] - sigma_t) / (2.f * s[ST_SIG]);   // d total / d spread
-    float gcx = lam[2] * wS * 2.f * (cx - s[ST_GX]) + koff * (sgx * (s[ST_DOXX] + 1.f) + sgy * s[ST_DOYX]) +
+    float gcx = lam[2] * w3S * 2.f * (cx - s[ST_GX]) + koff * (sgx * (s[ST_DOXX] + 1.f) + sgy * s[ST_DOYX]) +
                 kvar * (-2.f) * (s[ST_QX] - cx * s[ST_QSUM]);
-    float gcy = lam[2] * wS * 2.f * (cy - s[ST_GY]) + koff * (sgx * s[ST_DOXY] + sgy * (s[ST_DOYY] + 1.f)) +
+    float gcy = lam[2] * w3S * 2.f * (cy - s[ST_GY]) + koff * (sgx * s[ST_DOXY] + sgy * (s[ST_DOYY] + 1.f)) +
                 kvar * (-2.f) * (s[ST_QY] - cy * s[ST_QSUM]);
-    const float khm = lam[0] * wS * 2.f / (float)n;
+    const float khm = lam[0] * w3S * 2.f / (float)n;
     const float ksh = lam[5] * wS * 2.f * (s[ST_ENT] - tent);
     const float ubar = s[ST_UBAR], spread = s[ST_SPREAD], rinv = 1.f / (s[ST_R] + EPS8);
     // overlap partners of this joint
@@ -215,7 +220,7 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
         const int o = (i == k) ? j : i;
         const float* pr = pairs + ((size_t)b * 16 + p) * 4;
         const float O = pr[0], mn = pr[1], r = pr[2], v = pr[3];
-        const float kp = (r > 0.5f) ? G * lam[4] * v / den : 0.f;
+        const float kp = (r > lam[6]) ? G * lam[4] * v / den : 0.f;
         const float sk = s[ST_SSUM], so = ws[((size_t)b * K + o) * PK_LOSS_STAT + ST_SSUM];
         const float ind = sk < so ? 1.f : (sk == so ? 0.5f : 0.f);
         other[np] = o;

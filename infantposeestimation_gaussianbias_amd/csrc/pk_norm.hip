@@ -233,6 +233,9 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
                          const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
                          int64_t rows, int C, int relu, void* stream) {
     PK_REQUIRE(dy && raw && save_mean && save_rstd && gamma && partial && sums && dgamma && dbeta && dx, "pk_bn_bwd: null pointer");
+    // relu: bit 0 = the forward applied ReLU; bit 1 = eval-mode BatchNorm (running statistics are constants: no batch-mean terms)
+    const int eval_mode = relu & 2;
+    relu &= 1;
     PK_REQUIRE(!relu || y_act, "pk_bn_bwd: relu needs the activated output");
     PK_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0, "pk_bn_bwd: bad sizes");
     PK_SUPPORTED(C <= BNR_MAXC && C / 8 <= 256, "pk_bn_bwd: C=%d too large", C);
@@ -247,7 +250,7 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     size_t gb = (chunks + 255) / 256;
     if (gb > 4096) gb = 4096;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)gb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw,
-                       save_mean, save_rstd, gamma, sums, 1.f / (float)rows, (uint4*)dx, (uint4*)dresidual, chunks, C / 8, relu);
+                       save_mean, save_rstd, gamma, sums, eval_mode ? 0.f : 1.f / (float)rows, (uint4*)dx, (uint4*)dresidual, chunks, C / 8, relu);
     return pk_launch_status("pk_bn_bwd");
 }
 

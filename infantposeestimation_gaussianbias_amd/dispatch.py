@@ -64,7 +64,8 @@ def ops():
 
 
 # the network ops themselves (they refuse to run outside a scope: nnops._wc() raises without an active weight cache)
-from .nnops import backward_milestone, conv_bn_act, drop_scales, exchange, head_out, to_features, window_block  # noqa: E402,F401
+from .nnops import (backward_milestone, conv_bn_act, drop_scales, exchange, head_out, mlp_rows, to_features, window_attention_tokens,  # noqa: E402,F401
+                    window_block)
 
 
 def to_public(x):
@@ -78,6 +79,9 @@ def from_public(x):
     ops()
     if x.dtype != nnops.ACT_DTYPE:
         B, C, H, W = x.shape
+        if x.requires_grad and torch.is_grad_enabled() and C % 8 == 0:
+            # a leaf module called on its own with a differentiable fp32 tensor (public surface): keep autograd's chain through the cast
+            return x.permute(0, 2, 3, 1).to(nnops.ACT_DTYPE).contiguous()
         return nnops.to_features(x, cpad=-(-C // 8) * 8)
     return x.permute(0, 2, 3, 1).contiguous()
 

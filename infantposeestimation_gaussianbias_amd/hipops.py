@@ -143,16 +143,19 @@ class _FusionLoss(torch.autograd.Function):
     """L1/L2 forward + hand-derived backward (fusion_head.py:745-806). Returns the 7 loss values as one tensor."""
 
     @staticmethod
-    def forward(ctx, hm, off, var, target, weight, gt, in_w, in_h, sigma_t, lambdas):
+    def forward(ctx, hm, off, var, target, weight, gt, in_w, in_h, sigma_t, lambdas, use_target_weight=True):
         hm, off, var = _chk(hm, name="heatmaps"), _chk(off, name="offsets"), _chk(var, name="variances")
         target, weight, gt = _chk(target), _chk(weight), _chk(gt)
         B, K, H, W = hm.shape
         if off.shape != (B, K, 2, H, W) or var.shape != hm.shape or target.shape != hm.shape or weight.numel() != B * K or gt.shape != (B, K, 2):
             raise _lib.PoseKernelError("fusion loss: inconsistent shapes")
+        if lambdas.numel() == 6:           # term weights only: default overlap threshold (fusion_head.py:404)
+            lambdas = torch.cat([lambdas.float(), lambdas.new_full((1,), 0.5, dtype=F32)])
+        lambdas = _chk(lambdas.float(), name="lambdas")
         ws = torch.empty(loss_ws_floats(B, K), dtype=F32, device=hm.device)
         losses = torch.empty(7, dtype=F32, device=hm.device)
         call("pk_fusion_loss_fwd", hm, off, var, target, weight, gt, ws, losses, B, K, H, W, float(in_w), float(in_h), float(sigma_t),
-             lambdas, stream_ptr())
+             lambdas, 1 if use_target_weight else 0, stream_ptr())
         ctx.save_for_backward(hm, off, var, target, weight, ws, lambdas)
         ctx.sigma_t = float(sigma_t)
         return losses
@@ -163,14 +166,15 @@ class _FusionLoss(torch.autograd.Function):
         B, K, H, W = hm.shape
         # d(sum_i g_i * loss_i): entries 0..5 are the weighted terms and entry 6 their sum, so the per-term
         # multipliers are lambdas*(g[:6]+g[6]); the kernel takes them as "lambdas" with grad_total = 1.
-        eff = (lambdas * (g[:6] + g[6])).contiguous()
+        eff = torch.cat([lambdas[:6] * (g[:6] + g[6]), lambdas[6:7]]).contiguous()
         dhm, doff, dvar = torch.empty_like(hm), torch.empty_like(off), torch.empty_like(var)
         call("pk_fusion_loss_bwd", hm, off, var, target, weight, ws, None, dhm, doff, dvar, B, K, H, W, ctx.sigma_t, eff, stream_ptr())
-        return dhm, doff, dvar, None, None, None, None, None, None, None
+        return dhm, doff, dvar, None, None, None, None, None, None, None, None
 
 
-def fusion_loss(hm, off, var, target, weight, gt, input_size, sigma_t, lambdas_dev):
-    return _FusionLoss.apply(hm, off, var, target, weight, gt, float(input_size[0]), float(input_size[1]), sigma_t, lambdas_dev)
+def fusion_loss(hm, off, var, target, weight, gt, input_size, sigma_t, lambdas_dev, use_target_weight=True):
+    return _FusionLoss.apply(hm, off, var, target, weight, gt, float(input_size[0]), float(input_size[1]), sigma_t, lambdas_dev,
+                             bool(use_target_weight))
 
 
 class _PixelLoss(torch.autograd.Function):

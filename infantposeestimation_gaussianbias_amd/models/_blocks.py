@@ -36,6 +36,11 @@ class Residual(nn.Module):
             self.conv2, self.bn2 = conv(planes, planes, 3), nn.BatchNorm2d(planes)
 
     def forward(self, x):
+        """Internal NHWC bf16 map in/out when called by a backbone (inside its scope); a public (B,C,H,W) tensor when called on its
+        own, like the reference's BasicBlock / Bottleneck (hrnet.py:12-103)."""
+        if not nnops._ACTIVE:
+            with nnops.scope(self):
+                return nnops.to_public(self.forward(nnops.from_public(x)))
         tr = self.training
         y = nnops.conv_bn_act(x, self.conv1, self.bn1, True, None, tr)
         if not self.bottleneck:

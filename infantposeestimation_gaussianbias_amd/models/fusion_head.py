@@ -20,13 +20,14 @@ class SoftArgmax2D(nn.Module):
 
     def __init__(self, beta: float = 1.0):
         super().__init__()
-        if beta != 1.0:
-            raise ValueError("SoftArgmax2D: only beta=1.0 is supported")
         self.beta = beta
 
     def forward(self, heatmaps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
         one = torch.full((1,), 40.0, device=heatmaps.device)          # sigmoid(40) == 1: pure global soft-argmax
-        return hipops.softargmax_refine_decode(heatmaps.float(), None, one, None, radius=0)
+        co, sc = hipops.softargmax_refine_decode(heatmaps.float(), None, one, None, radius=0)
+        if self.beta != 1.0:      # coordinates from softmax(beta * H), scores stay the raw maxima (fusion_head.py:50-69); decode-time only
+            co, _ = hipops.softargmax_refine_decode((heatmaps.float() * self.beta).contiguous(), None, one, None, radius=0)
+        return co, sc
 
 
 class SubPixelRefinement(nn.Module):
@@ -112,8 +113,6 @@ class GaussianDistributionConstraint(nn.Module):
 
     def __init__(self, target_sigma: float = 2.0, overlap_threshold: float = 0.5):
         super().__init__()
-        if overlap_threshold != 0.5:
-            raise ValueError("overlap_threshold is fixed at 0.5 in the fused kernel")
         self.target_sigma, self.overlap_threshold = target_sigma, overlap_threshold
 
 
@@ -124,20 +123,18 @@ class FusionPoseLoss(nn.Module):
                  variance_weight: float = 0.1, overlap_weight: float = 0.05, shape_weight: float = 0.05,
                  target_sigma: float = 2.0, use_target_weight: bool = True):
         super().__init__()
-        if not use_target_weight:
-            raise ValueError("FusionPoseLoss: use_target_weight=False is not implemented in the fused kernel")
         self.heatmap_weight, self.offset_weight, self.peak_weight = heatmap_weight, offset_weight, peak_weight
         self.variance_weight, self.overlap_weight, self.shape_weight = variance_weight, overlap_weight, shape_weight
         self.use_target_weight = use_target_weight
         self.gaussian_constraint = GaussianDistributionConstraint(target_sigma)
         self.soft_argmax = SoftArgmax2D()
-        self.register_buffer("_lambdas", torch.tensor([heatmap_weight, offset_weight, peak_weight, variance_weight,
-                                                       overlap_weight, shape_weight], dtype=torch.float32), persistent=False)
+        self.register_buffer("_lambdas", torch.tensor([heatmap_weight, offset_weight, peak_weight, variance_weight, overlap_weight, shape_weight,
+                                                       self.gaussian_constraint.overlap_threshold], dtype=torch.float32), persistent=False)
 
     def forward(self, outputs, target_heatmaps, target_weight, gt_keypoints, input_size=(192, 256), heatmap_size=(48, 64)):
         vals = hipops.fusion_loss(outputs["heatmaps"], outputs["offsets"], outputs["variances"], target_heatmaps.float(),
                                   target_weight.float(), gt_keypoints.float(), input_size, self.gaussian_constraint.target_sigma,
-                                  self._lambdas)
+                                  self._lambdas, self.use_target_weight)
         return {n: vals[i] for i, n in enumerate(self.NAMES)}
 
 

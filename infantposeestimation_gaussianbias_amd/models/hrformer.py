@@ -27,6 +27,15 @@ class WindowAttentionParams(nn.Module):
                              (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1))
         self.qkv = nn.Linear(dim, dim * 3)
         self.proj = nn.Linear(dim, dim)
+        self.num_heads = heads
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B_*, 49, C) window tokens -> same shape (hrformer.py:174-200): qkv, scaled QK^T + relative position bias, softmax, AV, proj."""
+        B_, N, C = x.shape
+        if N != 49:
+            raise ValueError("WindowAttention: windows of 7x7 = 49 tokens")
+        with nnops.scope(self):
+            return nnops.window_attention_tokens(x.reshape(B_ * N, C).to(torch.bfloat16), self, self.num_heads).view(B_, N, C)
 
 
 class MlpParams(nn.Module):
@@ -34,6 +43,11 @@ class MlpParams(nn.Module):
         super().__init__()
         self.fc1 = nn.Linear(dim, hidden)
         self.fc2 = nn.Linear(hidden, dim)
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(..., C) -> (..., C): fc2(GELU_erf(fc1(x))) (hrformer.py:38-64; dropout p = 0)."""
+        with nnops.scope(self):
+            return nnops.mlp_rows(x.reshape(-1, x.shape[-1]).to(torch.bfloat16), self).view(*x.shape[:-1], self.fc2.weight.shape[0])
 
 
 class HRFormerBlock(nn.Module):
@@ -44,6 +58,17 @@ class HRFormerBlock(nn.Module):
         self.attn = WindowAttentionParams(dim, heads)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MlpParams(dim, int(dim * mlp_ratio))
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """(B,C,H,W) -> (B,C,H,W) (hrformer.py:262-293): x + DropPath(attn(LN1(x))), then + DropPath(mlp(LN2(.))); DropPath draws two
+        per-sample masks in training mode (hrformer.py:15-35)."""
+        with nnops.scope(self):
+            t = nnops.from_public(x)
+            s1 = s2 = None
+            if self.training and self.drop_prob > 0:
+                sc = nnops.drop_scales(2, t.shape[0], self.drop_prob, t.device)
+                s1, s2 = sc[0], sc[1]
+            return nnops.to_public(nnops.window_block(t, self, self.heads, s1, s2))
 
 
 class HRFormerModule(nn.Module):
@@ -146,6 +171,9 @@ class HRFormer(nn.Module):
             # run backward (only output 0 of the last stage is consumed, hrformer.py:776 / hrnet.py:441)
             nnops.backward_milestone(ys if s < 4 else ys[:1])
         return ys[0]
+
+
+WindowAttention, Mlp = WindowAttentionParams, MlpParams          # the reference's class names (hrformer.py:38,117)
 
 
 def hrformer_base(pretrained: bool = False, **kwargs) -> HRFormer:

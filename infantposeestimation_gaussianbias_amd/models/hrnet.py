@@ -75,6 +75,20 @@ class HRNet(nn.Module):
         return ys[0]
 
 
+def BasicBlock(inplanes: int, planes: int, stride: int = 1, downsample=None) -> Residual:
+    """hrnet.py:12-53 (stride / downsample are never used with BasicBlock by the reference's builders)."""
+    if stride != 1 or downsample is not None:
+        raise ValueError("BasicBlock: stride 1 without downsample (the only form the reference builds)")
+    return Residual(inplanes, planes, False)
+
+
+def Bottleneck(inplanes: int, planes: int, stride: int = 1, downsample=None) -> Residual:
+    """hrnet.py:56-103: expansion 4; `downsample` (any module) selects the 1x1 conv + BN projection of the identity path."""
+    if stride != 1:
+        raise ValueError("Bottleneck: stride 1 (the only form the reference builds)")
+    return Residual(inplanes, planes, True, project=downsample is not None)
+
+
 def hrnet_w32(pretrained: bool = False) -> HRNet:
     return HRNet(base_channels=32)
 

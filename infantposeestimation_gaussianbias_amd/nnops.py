@@ -408,8 +408,6 @@ class _ConvBnAct(torch.autograd.Function):
     def backward(ctx, dy):
         x, raw, y, mean, rstd, gamma, wd = ctx.saved_tensors
         stride, relu, training, has_res, Cin_real, ksize, (B, Hs, Ws, Ho, Wo) = ctx.meta
-        if not training:
-            raise _lib.PoseKernelError("conv_bn_act: backward through eval-mode BatchNorm is not implemented")
         dev, Cout, Cin, M = dy.device, raw.shape[-1], x.shape[-1], B * Ho * Wo
         dy = dy.contiguous()
         nb = _lib.lib.pk_bn_bwd_blocks(M)
@@ -418,7 +416,9 @@ class _ConvBnAct(torch.autograd.Function):
         (dgamma, sg), (dbeta, sb) = _sink(g_p), _sink(b_p)
         draw = _e(raw.shape, BF16, dev)
         dres = _e(raw.shape, BF16, dev) if has_res else None
-        call("pk_bn_bwd", dy, y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, dres, M, Cout, 1 if relu else 0, stream_ptr())
+        # (eval mode, bit 1: the running statistics are constants, the input gradient is gamma * rstd * g without the batch-mean terms)
+        call("pk_bn_bwd", dy, y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, dres, M, Cout, (1 if relu else 0) | (0 if training else 2),
+             stream_ptr())
         dx = _conv_dgrad(draw, wd, Cin, ksize, stride, (Hs, Ws)) if ctx.needs_input_grad[0] else None
         if Cin != Cin_real:                # stem: 3 real input channels inside 8-channel pixels
             dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo))[:, :Cin_real].contiguous()
@@ -642,6 +642,81 @@ class _MlpHalf(torch.autograd.Function):
 def _fused_widths(var, default):
     import os
     return tuple(int(v) for v in os.environ.get(var, default).split(",") if v.strip())
+
+
+class _WindowAttnOnly(torch.autograd.Function):
+    """proj(window_attention(qkv(tokens))) on window-ordered tokens (B_*49, C): the reference's WindowAttention.forward by itself
+    (hrformer.py:174-200), without the block's LayerNorm / window partition / residual."""
+
+    @staticmethod
+    def forward(ctx, tok, table, wqkv, bqkv, wproj, bproj, heads):
+        ctx.params = (table, wqkv, bqkv, wproj, bproj)
+        wc = _wc()
+        tok = tok.contiguous()
+        Mw, C = tok.shape
+        nw = Mw // (WS * WS)
+        qkv = _linear(tok, wc.fwd[id(wqkv)], Mw, 3 * C, C, bias=bqkv)
+        o = _e((Mw, C), BF16, tok.device)
+        lse = _e((nw * heads * WS * WS,), F32, tok.device)
+        call("pk_window_attn_fwd", qkv, table, o, lse, nw, heads, C, 0.0, stream_ptr())
+        y = _linear(o, wc.fwd[id(wproj)], Mw, C, C, bias=bproj)
+        ctx.save_for_backward(tok, qkv, o, lse, table, wc.dgrad[id(wqkv)], wc.dgrad[id(wproj)])
+        ctx.heads = heads
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        tok, qkv, o, lse, table, wqkv_t, wproj_t = ctx.saved_tensors
+        heads, (Mw, C), dev = ctx.heads, tok.shape, dy.device
+        nw = Mw // (WS * WS)
+        dy = dy.contiguous()
+        ptab, pwqkv, pbqkv, pwproj, pbproj = ctx.params
+        d_o = _linear(dy, wproj_t, Mw, C, C)
+        dbproj, dwproj = _e((C,), F32, dev), None
+        dwproj = _wgrad(o, dy, C, C, 1, 1, None, M=Mw, dbias=dbproj)
+        dqkv, dtable = _e((Mw, 3 * C), BF16, dev), _e(tuple(table.shape), F32, dev)
+        part = _e((_lib.lib.pk_window_attn_bwd_ws_floats(nw, heads),), F32, dev)
+        call("pk_window_attn_bwd", qkv, table, o, d_o, lse, dqkv, part, dtable, nw, heads, C, 0.0, stream_ptr())
+        dtok = _linear(dqkv, wqkv_t, Mw, C, 3 * C)
+        dbqkv = _e((3 * C,), F32, dev)
+        dwqkv = _wgrad(tok, dqkv, 3 * C, C, 1, 1, None, M=Mw, dbias=dbqkv)
+        return dtok, dtable, dwqkv, dbqkv, dwproj, dbproj, None
+
+
+class _MlpOnly(torch.autograd.Function):
+    """fc2(gelu(fc1(x))) on rows (M, C): the reference's Mlp.forward by itself (hrformer.py:38-64)."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        wc = _wc()
+        x = x.contiguous()
+        M, C = x.shape
+        Hd = w1.shape[0]
+        z = _e((M, Hd), BF16, x.device)
+        h = _linear(x, wc.fwd[id(w1)], M, Hd, C, bias=b1, preact=z, act=1)
+        y = _linear(h, wc.fwd[id(w2)], M, w2.shape[0], Hd, bias=b2)
+        ctx.save_for_backward(x, z, h, wc.dgrad[id(w1)], wc.dgrad[id(w2)])
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, h, w1_t, w2_t = ctx.saved_tensors
+        (M, C), Hd, N, dev = x.shape, z.shape[1], dy.shape[1], dy.device
+        dy = dy.contiguous()
+        dz = _linear(dy, w2_t, M, Hd, N, gelu_of=z)
+        db2, db1 = _e((N,), F32, dev), _e((Hd,), F32, dev)
+        dw2 = _wgrad(h, dy, N, Hd, 1, 1, None, M=M, dbias=db2)
+        dx = _linear(dz, w1_t, M, C, Hd)
+        dw1 = _wgrad(x, dz, Hd, C, 1, 1, None, M=M, dbias=db1)
+        return dx, dw1, db1, dw2, db2
+
+
+def window_attention_tokens(tok, attn, heads):
+    return _WindowAttnOnly.apply(tok, attn.relative_position_bias_table, attn.qkv.weight, attn.qkv.bias, attn.proj.weight, attn.proj.bias, heads)
+
+
+def mlp_rows(x2d, mlp):
+    return _MlpOnly.apply(x2d, mlp.fc1.weight, mlp.fc1.bias, mlp.fc2.weight, mlp.fc2.bias)
 
 
 def fused_mlp_enabled(C, c_real=0):

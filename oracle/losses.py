@@ -50,7 +50,7 @@ def sample_border(planes, cx, cy):
 
 
 def fusion_pose_loss(hm, offsets, variances, target, weight, gt_keypoints, input_size, sigma_t=2.0,
-                     lambdas=FUSION_WEIGHTS, overlap_threshold=0.5):
+                     lambdas=FUSION_WEIGHTS, overlap_threshold=0.5, use_target_weight=True):
     """All seven entries of `FusionPoseLoss.forward` (already multiplied by their λ), as a dict.
 
     hm/target/variances (B,K,H,W), offsets (B,K,2,H,W), weight (B,K,1), gt (B,K,2) input-px,
@@ -61,10 +61,13 @@ def fusion_pose_loss(hm, offsets, variances, target, weight, gt_keypoints, input
     c, P = soft_argmax(hm)
     g = torch.stack([gt_keypoints[..., 0] * (W / input_size[0]), gt_keypoints[..., 1] * (H / input_size[1])], -1)
 
-    l_hm = (w * ((hm - target) ** 2).mean((2, 3))).sum() / S
     sampled = sample_border(offsets, c[..., 0], c[..., 1])
-    l_off = (w * torch.nn.functional.smooth_l1_loss(sampled, g - c, reduction="none").mean(-1)).sum() / S
-    l_peak = (w * ((c - g) ** 2).sum(-1)).sum() / S
+    e_hm, e_off = ((hm - target) ** 2).mean((2, 3)), torch.nn.functional.smooth_l1_loss(sampled, g - c, reduction="none").mean(-1)
+    e_peak = ((c - g) ** 2).sum(-1)
+    if use_target_weight:
+        l_hm, l_off, l_peak = (w * e_hm).sum() / S, (w * e_off).sum() / S, (w * e_peak).sum() / S
+    else:       # fusion_head.py:653-657, 708-712, 739-743: plain means over (B, K); the constraint terms stay weighted
+        l_hm, l_off, l_peak = e_hm.mean(), e_off.mean(), e_peak.mean()
 
     xs, ys = _grids(H, W, hm)
     pos = torch.relu(hm)

@@ -713,6 +713,15 @@ def cap_extra():
     meta["eval"] = {"image_ids": ids, "ann_ids": anns, "predictions": ev.predictions, "gts": gts,
                     "metrics": {k: float(v) for k, v in metrics.items()}}
     save("extra_r02.npz", **out)
+    # ---- L1 with use_target_weight=False (fusion_head.py:653-657,708-712,739-743): values + input gradients
+    from models import fusion_head as fh
+    hm, off, var, tgt, w, gt = synth_loss_inputs("utw", 2, 17, 32, 24, 96, 128, True)
+    hmv, offv, varv = T(hm).requires_grad_(True), T(off).requires_grad_(True), T(var).requires_grad_(True)
+    lo = fh.FusionPoseLoss(use_target_weight=False)({"heatmaps": hmv, "offsets": offv, "variances": varv}, T(tgt), T(w), T(gt), (96, 128), (24, 32))
+    lo["total_loss"].backward()
+    names = ["heatmap_loss", "offset_loss", "peak_loss", "variance_loss", "overlap_loss", "shape_loss", "total_loss"]
+    save("loss_utw_r02.npz", hm=hm, off=off, var=var, tgt=tgt, w=w, gt=gt, losses=np.array([float(lo[n]) for n in names]),
+         g_hm=N(hmv.grad), g_off=N(offv.grad), g_var=N(varv.grad))
     return meta
 
 

@@ -675,3 +675,105 @@ def test_fused_attention_half_backward_vs_oracle_and_unfused(N, Cc, heads, B, H,
     # the bar of the block-level golden tests; the two kernel paths round at the same places and agree to 2e-2
     assert all(v < 3e-2 for v in rep.values()), rep
     assert all(v < 2e-2 for v in repu.values()), repu
+
+
+# ------------------------------------------------------------------------------------------------ public module surface
+def test_module_forward_surface_vs_oracle(golden):
+    """The reference's leaf modules called on their own (hrformer.py HRFormerBlock / WindowAttention / Mlp, hrnet.py BasicBlock): public
+    (B,C,H,W) / token tensors in and out, forward + backward against the fp32 oracle / golden numbers."""
+    from infantposeestimation_gaussianbias_amd.models import hrformer, hrnet
+    from oracle import nets as onet
+    z, meta = golden("attn_blocks.npz"), golden("meta.json")["attn"]["blk_a"]
+    blk = hrformer.HRFormerBlock(meta["C"], meta["heads"])
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(meta["spec"], 2).items()})
+    blk = blk.to(DEV).train()
+    x = torch.from_numpy(z["blk_a_x"]).to(DEV).requires_grad_(True)                 # (B,C,H,W) fp32, like the reference's call
+    y = blk(x)
+    assert y.shape == x.shape and err(C(y), torch.from_numpy(z["blk_a_y"])) < 3e-2
+    y.float().backward(torch.from_numpy(z["blk_a_gy"]).to(DEV))
+    assert err(C(x.grad), torch.from_numpy(z["blk_a_gx"])) < 3e-2
+    # WindowAttention / Mlp on window tokens
+    torch.manual_seed(1)
+    att = hrformer.WindowAttention(32, 1).to(DEV)
+    tok = rnd(3, 49, 32, seed=2)
+    P = {"a." + k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point) for k, v in att.state_dict().items()}
+    tr = tok.clone().requires_grad_(True)
+    ref = onet.window_attention(tr, P, "a", 1)
+    g = rnd(*ref.shape, seed=3)
+    ref.backward(g)
+    td = tok.to(DEV).requires_grad_(True)
+    out = att(td)
+    out.float().backward(g.to(DEV))
+    assert out.shape == (3, 49, 32) and err(C(out), ref.detach()) < 2e-2 and err(C(td.grad), tr.grad) < 3e-2
+    for k, p in att.named_parameters():
+        assert err(C(p.grad), P["a." + k].grad) < 3e-2, k
+    mlp = hrformer.Mlp(32, 128).to(DEV)
+    xm = rnd(5, 7, 32, seed=4)
+    refm = F.gelu(xm @ mlp.fc1.weight.detach().cpu().T + mlp.fc1.bias.detach().cpu()) @ mlp.fc2.weight.detach().cpu().T + mlp.fc2.bias.detach().cpu()
+    assert err(C(mlp(xm.to(DEV))), refm) < 2e-2
+    # BasicBlock on a public tensor, train mode (golden basic_tr)
+    zz, mm = golden("modules.npz"), golden("meta.json")["modules"]["basic_tr"]
+    bb = hrnet.BasicBlock(8, 8)
+    bb.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(mm["spec"], 3).items()})
+    bb = bb.to(DEV).train()
+    yb = bb(torch.from_numpy(zz["basic_tr_x0"]).to(DEV))
+    assert yb.shape == zz["basic_tr_y0"].shape and err(C(yb), torch.from_numpy(zz["basic_tr_y0"])) < 3e-2
+
+
+def test_eval_mode_batchnorm_backward(N):
+    """Backward through conv + eval-mode BatchNorm (running statistics are constants): dx, dW, dgamma, dbeta vs autograd on the CPU."""
+    torch.manual_seed(7)
+    conv, bn = torch.nn.Conv2d(16, 24, 3, 1, 1, bias=False), torch.nn.BatchNorm2d(24)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight * 2))
+        bn.weight.copy_(torch.rand(24) + 0.5)
+        bn.bias.copy_(torch.randn(24) * 0.2)
+        bn.running_mean.copy_(torch.randn(24) * 0.1)
+        bn.running_var.copy_(torch.rand(24) + 0.5)
+    conv.eval(), bn.eval()
+    x, r, gy = rnd(2, 16, 9, 7, seed=1), rnd(2, 24, 9, 7, seed=2), rnd(2, 24, 9, 7, seed=3)
+    xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    from oracle import nets as onet
+    y_ref = torch.relu(bn(onet.bf16_storage(conv(xr))) + rr)          # the kernel normalises the bf16-stored conv output
+    y_ref.backward(gy)
+    import copy
+    m = Holder(c=copy.deepcopy(conv), b=copy.deepcopy(bn)).to(DEV).eval()
+    for p in m.parameters():
+        p.grad = None
+    with N.use_weights(m):
+        xd, rd = nhwc(x).requires_grad_(True), nhwc(r).requires_grad_(True)
+        y = N.conv_bn_act(xd, m.c, m.b, True, rd, False)
+        y.backward(nhwc(gy))
+    assert err(nchw(y), y_ref.detach()) < 1e-2
+    assert err2(nchw(xd.grad), xr.grad) < 2e-2 and err2(nchw(rd.grad), rr.grad) < 2e-2
+    assert err2(C(m.c.weight.grad), conv.weight.grad) < 2e-2
+    assert err2(C(m.b.weight.grad), bn.weight.grad) < 2e-2 and err2(C(m.b.bias.grad), bn.bias.grad) < 2e-2
+    assert torch.equal(m.b.running_mean.cpu(), bn.running_mean) and int(m.b.num_batches_tracked) == 0
+
+
+def test_softargmax_beta_and_overlap_threshold_vs_oracle(golden):
+    """SoftArgmax2D(beta != 1) and GaussianDistributionConstraint(overlap_threshold != 0.5) (fusion_head.py:33-36,400-404)."""
+    from infantposeestimation_gaussianbias_amd.models import fusion_head as fh
+    from oracle import losses as olos
+    z = golden("loss_utw_r02.npz")
+    hm = torch.from_numpy(z["hm"])
+    co, sc = fh.SoftArgmax2D(beta=2.5)(hm.to(DEV))
+    co_ref, _ = olos.soft_argmax(hm * 2.5)
+    assert np.abs(C(co).numpy() - co_ref.numpy()).max() < 2e-3 and torch.equal(sc.cpu(), hm.flatten(2).max(-1)[0])
+
+    class LowThreshold(fh.FusionPoseLoss):           # the reference wires the threshold through GaussianDistributionConstraint's constructor
+        def __init__(self):
+            super().__init__(overlap_weight=1.0)
+            self.gaussian_constraint = fh.GaussianDistributionConstraint(2.0, 0.05)
+            self._lambdas[6] = 0.05
+
+    out = LowThreshold().to(DEV)({"heatmaps": G(z["hm"]), "offsets": G(z["off"]), "variances": G(z["var"])}, G(z["tgt"]), G(z["w"]), G(z["gt"]),
+                                 (96, 128), (24, 32))
+    ref = olos.fusion_pose_loss(hm, torch.from_numpy(z["off"]), torch.from_numpy(z["var"]), torch.from_numpy(z["tgt"]), torch.from_numpy(z["w"]),
+                                torch.from_numpy(z["gt"]), (96, 128), lambdas=(1.0, 1.0, 0.5, 0.1, 1.0, 0.05), overlap_threshold=0.05)
+    assert float(ref["overlap_loss"]) > 0
+    assert abs(float(out["overlap_loss"]) - float(ref["overlap_loss"])) < 1e-4 * max(1.0, abs(float(ref["overlap_loss"])))
+
+
+def G(a, dtype=torch.float32):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)

@@ -430,3 +430,17 @@ def test_evaluator_bookkeeping_vs_reference(golden):
         assert abs(og.oks(z["eval_pk"][i].astype(np.float64), gk[:, :2], gk[:, 2], g["area"]) - float(z["eval_oks"][i])) < 1e-12
     m = og.precision_metrics(meta["predictions"], meta["gts"])
     assert all(abs(m[k] - meta["metrics"][k]) < 1e-12 for k in ("AP", "AP50", "AP75")), (m, meta["metrics"])
+
+
+def test_fusion_loss_without_target_weight_vs_reference(golden):
+    """L1 with use_target_weight=False: the heatmap / offset / peak terms become plain (B,K) means, the constraint terms stay weighted."""
+    from oracle import losses as olos
+    z = golden("loss_utw_r02.npz")
+    hm, off, var = (torch.from_numpy(z[k]).requires_grad_(True) for k in ("hm", "off", "var"))
+    out = olos.fusion_pose_loss(hm, off, var, torch.from_numpy(z["tgt"]), torch.from_numpy(z["w"]), torch.from_numpy(z["gt"]), (96, 128),
+                                use_target_weight=False)
+    got = np.array([float(out[n]) for n in olos.NAMES])
+    assert np.allclose(got, z["losses"], rtol=1e-5, atol=1e-6), (got, z["losses"])
+    out["total_loss"].backward()
+    for t, k in ((hm, "g_hm"), (off, "g_off"), (var, "g_var")):
+        assert np.abs(t.grad.numpy() - z[k]).max() <= 1e-4 * max(1e-6, np.abs(z[k]).max()), k

@@ -651,6 +651,7 @@ struct WgradArgs {
     int g_rows_per_sample;
     float* bias_part;         // optional [S][N] fp32: column sums of the (scaled, gathered) G rows = bias gradient slabs
     int M, N, Cin, T, Hs, Ws, Ho, Wo, stride, pad, m_per_slice, ctiles;
+    int ntiles3, nslices3;    // k_wgrad3: output tiles per tap, number of M-slices
 };
 
 #define WG_MK 32
@@ -798,6 +799,143 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 
         }
 }
 
+// ------------------------------------------------------------------------------------------------ wide weight-gradient kernel
+// The 3x3 convolutions of the fusion head (256 -> 256 channels at 64x48, M = 196 608 pixels: 232 GFLOP each, five per step) ran
+// at 19 % of the MFMA peak on the 128 x 128 tile above: every (n-tile, c-tile, tap) workgroup streams its slice of G and X again
+// (36 x 100 MB per launch), 16 KB per 64 MFMAs = the CU's 64 B/clk L1 port at full MFMA rate, and a one-step register
+// prefetch does not cover an L2 round trip.  This kernel:
+//   * 256 (n) x 256 (c) output tile per 512-thread workgroup (8 waves as 4 x 2, 64 x 128 per wave: 128 accumulator registers):
+//     twice the MFMAs per staged byte, operand traffic 18 x 100 MB;
+//   * operands go global -> LDS by LDS-DMA (`buffer_load ... lds`, no VGPR round trip) into a FOUR-stage ring, three 32-row
+//     K-steps in flight ahead of the one being multiplied, one raw s_barrier per step with a counted `s_waitcnt vmcnt`, so the
+//     DMA stays in flight across the barrier;
+//   * tiles are row-major [32 rows][256 columns] (512-byte rows, what one DMA wave-instruction writes linearly: two rows per
+//     1 KiB piece) with the 16-byte chunks XOR-swizzled on the SOURCE side by swz(row) = 2 (row & 3) + 8 ((row >> 3) & 1): the
+//     transpose reads `ds_read_b64_tr_b16` of a 32-lane half (rows r..r+3 and r+8..r+11, 32 columns) then touch 32 distinct
+//     8-byte bank pairs (without it all rows alias: 8-way conflicts).
+// One workgroup per CU (128 KB of LDS), 1-D grid of 9 taps x S slices ~ one round of workgroups with equal work.
+#define W3_ROWS 32
+#define W3_STAGES 4
+__device__ __forceinline__ int w3_swz(int row) { return 2 * (row & 3) + 8 * ((row >> 3) & 1); }
+__device__ __forceinline__ bf16x8 w3_frag(const uint16_t* tile, int col0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+    const int row = 8 * g + q;
+    const int pchunk = ((col0 >> 3) + (pq >> 1)) ^ (2 * q + 8 * (g & 1));          // w3_swz(row) == w3_swz(row + 4)
+    const uint16_t* a0 = tile + row * 256 + pchunk * 8 + (pq & 1) * 4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 256));
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+__global__ void __launch_bounds__(512, 2) k_wgrad3(WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t w3_smem[];            // [stage][G tile 32 x 256 | X tile 32 x 256]
+    constexpr int TILE = W3_ROWS * 256;                                            // elements per operand tile (16 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    // XCD-aware placement (1-D grid): workgroups are dealt to the 8 XCDs round-robin by linear id, each XCD has its own 4 MB L2.  The 9
+    // taps (and the output tiles) of one M-slice read the same rows of G and X at about the same time, so they all go to ONE XCD
+    // (slice z = xcd + 8 * group).
+    const int xcd = blockIdx.x & 7, k_in = blockIdx.x >> 3, per_slice = 9 * p.ntiles3;
+    const int zslice = xcd + 8 * (k_in / per_slice), rem = k_in % per_slice;
+    if (zslice >= p.nslices3) return;            // padding workgroups of the last group (whole workgroup: no barrier was reached)
+    const int t = rem % 9, tile3 = rem / 9;
+    const int ntile = tile3 / p.ctiles, ctile = tile3 - ntile * p.ctiles;
+    const int n0 = ntile * 256, c0 = ctile * 256;
+    const int kh = t / 3, kw = t - kh * 3;
+    const int m_begin = zslice * p.m_per_slice;
+    const int m_end = min(p.M, m_begin + p.m_per_slice);
+    const int nsteps = (max(m_end - m_begin, 0) + W3_ROWS - 1) / W3_ROWS;
+    const int hw = p.Ho * p.Wo;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.g), 0, 0x7ffffff0, 0x00020000);
+    // this wave's DMA pieces: tile rows (4 wave + 2 j, + 1), j = 0, 1; lane -> (row within the pair, physical chunk).  The pixel
+    // coordinates of the lane's row are carried from step to step (+32 rows with carries): the first version recomputed them with two
+    // integer divisions per piece and step, ~200 VALU instructions per wave and step -- more issue time than the step's 32 MFMAs.
+    const int prow = lane >> 5, pchunk = lane & 31;
+    int pm[2], pb[2], poy[2], pox[2], colg[2], colx[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int row = 4 * wave + 2 * j + prow;
+        const int lch = pchunk ^ w3_swz(row);
+        pm[j] = m_begin + row;
+        pb[j] = pm[j] / hw;
+        const int r = pm[j] - pb[j] * hw;
+        poy[j] = r / p.Wo;
+        pox[j] = r - poy[j] * p.Wo;
+        colg[j] = n0 + lch * 8;
+        colx[j] = c0 + lch * 8;
+    }
+    int issued = 0;
+    auto issue_next = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int st = issued & (W3_STAGES - 1);
+        ++issued;
+        uint16_t* sg = w3_smem + st * 2 * TILE;
+        uint16_t* sx = sg + TILE;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const bool live = pm[j] < m_end;
+            const int iy = poy[j] * p.stride - p.pad + kh, ix = pox[j] * p.stride - p.pad + kw;
+            const bool in = live && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+            const unsigned og = live ? (unsigned)((pm[j] * p.N + colg[j]) * 2) : OOB_OFF;
+            const unsigned ox_ = in ? (unsigned)((((pb[j] * p.Hs + iy) * p.Ws + ix) * p.Cin + colx[j]) * 2) : OOB_OFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, (__attribute__((address_space(3))) void*)(sg + (4 * wave + 2 * j) * 256), 16, og, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sx + (4 * wave + 2 * j) * 256), 16, ox_, 0, 0, 0);
+            pm[j] += W3_ROWS;                       // next step: 32 rows further, with carries into (oy, b)
+            pox[j] += W3_ROWS;
+            while (pox[j] >= p.Wo) {
+                pox[j] -= p.Wo;
+                if (++poy[j] == p.Ho) {
+                    poy[j] = 0;
+                    ++pb[j];
+                }
+            }
+        }
+#endif
+    };
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // prologue: three steps in flight (steps beyond the slice issue out-of-range loads = zero tiles, so the counts stay uniform)
+    issue_next();
+    issue_next();
+    issue_next();
+    for (int s = 0; s < nsteps; ++s) {
+        // step s's four pieces of this wave have landed when at most the 8 younger ones are outstanding; the barrier then covers the
+        // other waves' pieces and guarantees everyone has finished reading stage (s - 1) & 3, which the next issue overwrites
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        const uint16_t* sg = w3_smem + (s & (W3_STAGES - 1)) * 2 * TILE;
+        const uint16_t* sx = sg + TILE;
+        bf16x8 gf[4], xf[8];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) gf[a] = w3_frag(sg, wn * 64 + a * 16, lane);
+#pragma unroll
+        for (int b = 0; b < 8; ++b) xf[b] = w3_frag(sx, wc * 128 + b * 16, lane);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the run-ahead zero tiles must have landed before the LDS is released
+    float* dst = p.part + (size_t)zslice * p.N * p.T * p.Cin;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int c = c0 + wc * 128 + b * 16 + (lane & 15);
+            const int n = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dst[((size_t)(n + r) * p.T + t) * p.Cin + c] = acc[a][b][r];
+        }
+}
+static inline bool wgrad_wide(int N, int Cin, int T) {
+    static const int on = getenv("PK_WGRAD_WIDE") ? atoi(getenv("PK_WGRAD_WIDE")) : 1;
+    return on && T == 9 && (N % 256) == 0 && (Cin % 256) == 0;
+}
+
 // out[...] = sum_s part[s][n][t][c]; layout 0: [N][T][Cin]; layout 1: OIHW = [N][Cin][T] (reference conv weight layout).
 // Block = 16 elements x 16 slice-lanes (lane r sums slices s = r mod 16, fixed-order combine): short dependency chains
 // even with hundreds of slices, still deterministic.
@@ -915,6 +1053,17 @@ extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
     static const int target = getenv("PK_WGRAD_WGS") ? atoi(getenv("PK_WGRAD_WGS")) : 2048;
     // (shorter slices for the low-resolution branches were measured: 64-row slices cost +1.3 ms per step in slab traffic)
     static const int min_rows = getenv("PK_WGRAD_ROWS") ? atoi(getenv("PK_WGRAD_ROWS")) : 256;
+    if (wgrad_wide(N, Cin, T)) {
+        // one 512-thread workgroup per CU (128 KB LDS ring): ~one round of equal-sized workgroups over the 256 CUs, in whole groups of
+        // 8 slices (one slice per XCD and group)
+        static const int wide_target = getenv("PK_WGRAD_WIDE_WGS") ? atoi(getenv("PK_WGRAD_WIDE_WGS")) : 256;
+        const int tiles3 = (N / 256) * (Cin / 256) * T;
+        int s3 = wide_target / tiles3 / 8 * 8;
+        if (s3 < 8) s3 = 8;
+        const int max3 = (M + 1023) / 1024;
+        if (s3 > max3) s3 = max3;
+        return s3 < 1 ? 1 : s3;
+    }
     int tn, tc;
     wgrad_tile2(N, Cin, T, tn, tc);
     const int tiles = ((N + tn - 1) / tn) * ((Cin + tc - 1) / tc) * T;
@@ -950,9 +1099,24 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     a.ctiles = (Cin + tc - 1) / tc;
     hipStream_t st = (hipStream_t)stream;
     PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
-    const dim3 grid(((N + tn - 1) / tn) * a.ctiles, a.T, S);
-    if (tn == 128) hipLaunchKernelGGL((k_wgrad2<128, 128, 32>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad2<64, 64, 32>), grid, dim3(256), 0, st, a);
+    if (wgrad_wide(N, Cin, a.T)) {
+        PK_SUPPORTED(!linear && n_bias == 0, "pk_wgrad_bf16: the wide 3x3 kernel has no bias-gradient path (convolutions here carry no bias)");
+        a.ctiles = Cin / 256;
+        a.ntiles3 = (N / 256) * a.ctiles;
+        a.nslices3 = S;
+        static bool attr_set = false;
+        constexpr int W3_LDS = W3_STAGES * 2 * W3_ROWS * 256 * 2;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void*)k_wgrad3, hipFuncAttributeMaxDynamicSharedMemorySize, W3_LDS);
+            PK_REQUIRE(e == hipSuccess, "pk_wgrad_bf16: cannot reserve %d bytes of LDS: %s", W3_LDS, hipGetErrorString(e));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_wgrad3, dim3(8 * ((S + 7) / 8) * 9 * a.ntiles3), dim3(512), W3_LDS, st, a);
+    } else {
+        const dim3 grid(((N + tn - 1) / tn) * a.ctiles, a.T, S);
+        if (tn == 128) hipLaunchKernelGGL((k_wgrad2<128, 128, 32>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_wgrad2<64, 64, 32>), grid, dim3(256), 0, st, a);
+    }
     if (!dw) return pk_launch_status("pk_wgrad_bf16");        // slabs only: the caller reduces them later (pk_reduce_many)
     const int total = N * a.T * Cin;
     const int w_blocks = (total + 15) / 16, b_blocks = dbias ? (n_bias + 15) / 16 : 0;

@@ -68,7 +68,11 @@ class Holder(torch.nn.Module):
                                                 (1, 16, 12, 256, 128, 3, 1), (2, 8, 6, 64, 32, 1, 1),
                                                 # M = 67 200 >= 65 536 with a half-filled last 256-row tile: the 256 x 128 workgroup
                                                 # tile (K >= 576, N % 128 == 0) for forward, and for dgrad in the second case
-                                                (6, 112, 100, 64, 128, 3, 1), (5, 120, 112, 128, 256, 3, 1)])
+                                                (6, 112, 100, 64, 128, 3, 1), (5, 120, 112, 128, 256, 3, 1),
+                                                # 256 -> 256 / 512 at 3x3: the wide weight-gradient kernel (256 x 256 tile, LDS-DMA ring): a
+                                                # slice shorter than one 32-row step, ragged slices, two n-tiles, stride 2
+                                                (1, 5, 4, 256, 256, 3, 1), (3, 23, 17, 256, 256, 3, 1), (2, 12, 10, 256, 512, 3, 1),
+                                                (2, 14, 10, 256, 256, 3, 2), (8, 64, 48, 256, 256, 3, 1)])
 def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
     from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
     conv = torch.nn.Conv2d(Cin, Cout, k, s, k // 2, bias=False)

@@ -32,6 +32,7 @@ extern "C" {
 
 int pk_version(void);                      /* 10000*major + 100*minor + patch */
 const char* pk_last_error_string(void);    /* thread-local; valid until the next failing call on this thread */
+int pk_marker(int id, void* stream);       /* profiling aid: empty launch of `id` workgroups that cuts a kernel trace into sections */
 
 /* ---- T1: COCOPoseDataset._generate_target (datasets/coco_dataset.py:185-250), batched ------------------
  * keypoints (B,K,2) f32 input-px; visible (B,K) f32 (COCO v: 0/1/2); lut = host-built patch values indexed
@@ -164,7 +165,9 @@ int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, c
  * accumulated from the tile already staged in LDS.                                                                       */
 /* dw == NULL: write the slabs only (weight slabs [S][N*k*k*Cin], then bias slabs [S][N] when n_bias > 0) and let the caller
  * reduce them later with pk_reduce_many.                                                                                  */
-int pk_wgrad_slices(int M, int N, int Cin, int T);
+/* pk_wgrad_slices: the slab count S of the launch pk_wgrad_bf16 will make for the same arguments (Hs = Ws = 0 for the linear
+ * form; flags bit 0 = a_rowmap given, bit 1 = g_rowmap given, bit 2 = g_scale given).                                         */
+int pk_wgrad_slices(int M, int N, int Cin, int ksize, int stride, int Hs, int Ws, int flags);
 int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, float* dbias, int n_bias,
                   const int32_t* a_rowmap, const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M, int N,
                   int Cin, int ksize, int stride, int B, int Hs, int Ws, int Ho, int Wo, int out_layout, void* stream);

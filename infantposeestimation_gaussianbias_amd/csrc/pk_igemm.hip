@@ -814,17 +814,33 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 
 //     transpose reads `ds_read_b64_tr_b16` of a 32-lane half (rows r..r+3 and r+8..r+11, 32 columns) then touch 32 distinct
 //     8-byte bank pairs (without it all rows alias: 8-way conflicts).
 // One workgroup per CU (128 KB of LDS), 1-D grid of 9 taps x S slices ~ one round of workgroups with equal work.
+// LDS reads of the DMA rings go through inline assembly.  The compiler cannot tell which LDS bytes an outstanding `buffer_load ...
+// lds` will write, so before any ds_read it can see it inserts `s_waitcnt vmcnt(0)` -- i.e. it drains the whole ring (including the
+// steps issued a moment ago) on every step and the loop runs at one memory round trip per step, however deep the ring is (this is
+// what held the first version of k_wgrad3 at 25 % of the MFMA peak).  The kernels below do their own accounting (counted vmcnt +
+// barrier before a stage is read), read through ring_tr(), and close each group of reads with ring_fence(), which waits for the LDS
+// data and, by naming the fragments as in/out operands, keeps the MFMAs behind it.
+__device__ __forceinline__ s16x4 ring_tr(const uint16_t* a) {
+    s16x4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void ring_fence(s16x4& a, s16x4& b, s16x4& c, s16x4& d, s16x4& e, s16x4& f, s16x4& g, s16x4& h) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d), "+v"(e), "+v"(f), "+v"(g), "+v"(h)::"memory");
+}
+__device__ __forceinline__ bf16x8 ring_join(const s16x4& lo, const s16x4& hi) {
+    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
 #define W3_ROWS 32
 #define W3_STAGES 4
 __device__ __forceinline__ int w3_swz(int row) { return 2 * (row & 3) + 8 * ((row >> 3) & 1); }
-__device__ __forceinline__ bf16x8 w3_frag(const uint16_t* tile, int col0, int lane) {
+__device__ __forceinline__ void w3_frag(const uint16_t* tile, int col0, int lane, s16x4& lo, s16x4& hi) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
     const int row = 8 * g + q;
     const int pchunk = ((col0 >> 3) + (pq >> 1)) ^ (2 * q + 8 * (g & 1));          // w3_swz(row) == w3_swz(row + 4)
     const uint16_t* a0 = tile + row * 256 + pchunk * 8 + (pq & 1) * 4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * 256));
-    return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    lo = ring_tr(a0);
+    hi = ring_tr(a0 + 4 * 256);
 }
 __global__ void __launch_bounds__(512, 2) k_wgrad3(WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) uint16_t w3_smem[];            // [stage][G tile 32 x 256 | X tile 32 x 256]
@@ -909,15 +925,31 @@ __global__ void __launch_bounds__(512, 2) k_wgrad3(WgradArgs p) {
         issue_next();
         const uint16_t* sg = w3_smem + (s & (W3_STAGES - 1)) * 2 * TILE;
         const uint16_t* sx = sg + TILE;
-        bf16x8 gf[4], xf[8];
+        s16x4 gl[4], gh[4], xl[8], xh[8];
 #pragma unroll
-        for (int a = 0; a < 4; ++a) gf[a] = w3_frag(sg, wn * 64 + a * 16, lane);
+        for (int a = 0; a < 4; ++a) w3_frag(sg, wn * 64 + a * 16, lane, gl[a], gh[a]);
 #pragma unroll
-        for (int b = 0; b < 8; ++b) xf[b] = w3_frag(sx, wc * 128 + b * 16, lane);
+        for (int b = 0; b < 4; ++b) w3_frag(sx, wc * 128 + b * 16, lane, xl[b], xh[b]);
+        ring_fence(gl[0], gh[0], gl[1], gh[1], gl[2], gh[2], gl[3], gh[3]);
+        ring_fence(xl[0], xh[0], xl[1], xh[1], xl[2], xh[2], xl[3], xh[3]);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int b = 4; b < 8; ++b) w3_frag(sx, wc * 128 + b * 16, lane, xl[b], xh[b]);      // in flight under the first 16 MFMAs
+        bf16x8 gf[4];
 #pragma unroll
-            for (int b = 0; b < 8; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < 4; ++a) gf[a] = ring_join(gl[a], gh[a]);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const bf16x8 xf = ring_join(xl[b], xh[b]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf, acc[a][b], 0, 0, 0);
+        }
+        ring_fence(xl[4], xh[4], xl[5], xh[5], xl[6], xh[6], xl[7], xh[7]);
+#pragma unroll
+        for (int b = 4; b < 8; ++b) {
+            const bf16x8 xf = ring_join(xl[b], xh[b]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf, acc[a][b], 0, 0, 0);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the run-ahead zero tiles must have landed before the LDS is released
     float* dst = p.part + (size_t)zslice * p.N * p.T * p.Cin;
@@ -934,6 +966,322 @@ __global__ void __launch_bounds__(512, 2) k_wgrad3(WgradArgs p) {
 static inline bool wgrad_wide(int N, int Cin, int T) {
     static const int on = getenv("PK_WGRAD_WIDE") ? atoi(getenv("PK_WGRAD_WIDE")) : 1;
     return on && T == 9 && (N % 256) == 0 && (Cin % 256) == 0;
+}
+
+// ------------------------------------------------------------------------------------------------ streaming weight-gradient kernels
+// Most weight gradients of the backbone are skinny GEMMs: M = 3 072 .. 219 520 rows against an N x Cin output of 32 .. 1 024 per
+// side, i.e. a few flops per operand byte -- streaming work.  k_wgrad2 stages through registers one step ahead, so a workgroup
+// covers a fraction of one memory round trip per step and the launcher needs >= 2 048 short slices to hide it; every slice writes
+// a whole fp32 copy of its output tile (2.2 GB of slabs per step, read again by k_reduce_many).  k_wgrad4 keeps the k_wgrad3
+// machinery (LDS-DMA ring with counted vmcnt across one raw barrier per step, source-side XOR swizzle, transpose reads) on
+// 64/128-wide tiles with 256 threads and two workgroups per CU: 3 (ring of 4) or 7 (ring of 8) steps in flight per workgroup, so
+// ~512 long slices fill the chip and the slab volume drops with the slice count.
+//   k_wgrad4<TN, TC>: single tap (linear layers, 1x1 convolutions), bias gradient = one extra MFMA against a ones fragment.
+//   k_wgrad4_3x3:     3x3 stride-1 convolutions, ALL NINE TAPS from one pass over G and X.  The K loop runs over PADDED pixel
+//     coordinates p = (b, py, px) of the (Hs+2) x (Ws+2) zero-bordered image: dW[n][kh][kw][c] = sum_p Gpad[p][n] * Xpad[p + (kh-1)
+//     (Ws+2) + (kw-1)][c], Gpad = 0 on the border, so every tap is the SAME 32 rows of G against a row-shifted window of one
+//     circular X buffer (256 rows: 51 rows of halo either side + the rows in flight); border rows are fetched with the
+//     out-of-range buffer offset (the DMA writes zeros).  64 x 64 output tile x 9 taps = 144 accumulator registers, waves split
+//     the c range so each wave reads 4 G fragments + 9 X fragments for 36 MFMAs.
+template <int W> __device__ __forceinline__ int w4_swz(int row) {            // in 16-byte chunks; uses row bits 0, 1, 3 only
+    return W == 128 ? 2 * (row & 3) + 8 * ((row >> 3) & 1) : 2 * ((row >> 1) & 1) + 4 * ((row >> 3) & 1);
+}
+template <int W> __device__ __forceinline__ int w4_elem(int row, int col0, int pq) {
+    return row * W + ((((col0 >> 3) + (pq >> 1)) ^ w4_swz<W>(row)) << 3) + (pq & 1) * 4;
+}
+template <int W> __device__ __forceinline__ void w4_frag(const uint16_t* tile, int col0, int lane, s16x4& lo, s16x4& hi) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
+    const uint16_t* a0 = tile + w4_elem<W>(8 * g + q, col0, pq);             // rows r and r + 4 share the swizzle (bit 2 is not used)
+    lo = ring_tr(a0);
+    hi = ring_tr(a0 + 4 * W);
+}
+__device__ __forceinline__ void ring_fence4(s16x4& a, s16x4& b, s16x4& c, s16x4& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+template <int N> __device__ __forceinline__ void w4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define W4_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
+
+template <int TN, int TC>
+__global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
+    constexpr int ST = (TN + TC <= 128) ? 8 : 4;                  // ring depth: 64 KB (64+64: 8 x 8 KB, 128+128: 4 x 16 KB), 48 KB otherwise
+    constexpr int PG = TN / 64, PX = TC / 64, PER = PG + PX;      // 1 KiB DMA pieces per wave and step
+    constexpr int RG = 512 / TN, RX = 512 / TC;                   // tile rows per piece
+    constexpr int NI = TN / 32, CI = TC / 32;                     // accumulator tiles per wave (waves 2 x 2)
+    constexpr int STAGE = 32 * (TN + TC);                         // elements
+    __shared__ __attribute__((aligned(1024))) uint16_t ring[ST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int xcd = blockIdx.x & 7, k_in = blockIdx.x >> 3;
+    const int zslice = xcd + 8 * (k_in / p.ntiles3), tile3 = k_in % p.ntiles3;
+    if (zslice >= p.nslices3) return;            // padding workgroups of the last group of 8 slices (whole workgroup, before any barrier)
+    const int ntile = tile3 / p.ctiles, ctile = tile3 - ntile * p.ctiles;
+    const int n0 = ntile * TN, c0 = ctile * TC;
+    const int m_begin = zslice * p.m_per_slice;
+    const int m_end = min(p.M, m_begin + p.m_per_slice);
+    const int nsteps = (max(m_end - m_begin, 0) + 31) / 32;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.g), 0, 0x7ffffff0, 0x00020000);
+    // this wave's pieces: G pieces wave + 4 j (j < PG), X pieces wave + 4 j (j < PX); lane -> (row in piece, physical chunk)
+    int gm[PG], xm[PX];
+    unsigned goff[PG], xoff[PX];
+    bool gcol[PG], xcol[PX];
+#pragma unroll
+    for (int j = 0; j < PG; ++j) {
+        const int row = (wave + 4 * j) * RG + lane / (TN / 8);
+        const int col = n0 + (((lane % (TN / 8)) ^ w4_swz<TN>(row)) << 3);
+        gm[j] = m_begin + row;
+        gcol[j] = col < p.N;
+        goff[j] = (unsigned)((gm[j] * p.N + col) * 2);
+    }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int row = (wave + 4 * j) * RX + lane / (TC / 8);
+        const int col = c0 + (((lane % (TC / 8)) ^ w4_swz<TC>(row)) << 3);
+        xm[j] = m_begin + row;
+        xcol[j] = col < p.Cin;
+        xoff[j] = (unsigned)((xm[j] * p.Cin + col) * 2);
+    }
+    const unsigned gstep = (unsigned)(64 * p.N), xstep = (unsigned)(64 * p.Cin);       // bytes per 32 rows
+    int issued = 0;
+    auto issue_next = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint16_t* sg = ring + (issued & (ST - 1)) * STAGE;
+        uint16_t* sx = sg + 32 * TN;
+        ++issued;
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, W4_LDS(sg + (wave + 4 * j) * 512), 16, (gcol[j] && gm[j] < m_end) ? goff[j] : OOB_OFF, 0, 0, 0);
+            gm[j] += 32;
+            goff[j] += gstep;
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, W4_LDS(sx + (wave + 4 * j) * 512), 16, (xcol[j] && xm[j] < m_end) ? xoff[j] : OOB_OFF, 0, 0, 0);
+            xm[j] += 32;
+            xoff[j] += xstep;
+        }
+#endif
+    };
+    f32x4 acc[NI][CI], accb[NI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a) {
+        accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < CI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = p.bias_part && ctile == 0 && wc == 0;          // wave-uniform
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+#pragma unroll
+    for (int j = 0; j < ST - 1; ++j) issue_next();       // steps beyond the slice fetch zero tiles: the counts stay uniform
+    for (int s = 0; s < nsteps; ++s) {
+        w4_wait_vm<(ST - 2) * PER>();                    // this wave's pieces of step s have landed ...
+        __builtin_amdgcn_s_barrier();                    // ... everyone's have, and everyone is done with stage (s - 1) % ST
+        issue_next();
+        const uint16_t* sg = ring + (s & (ST - 1)) * STAGE;
+        const uint16_t* sx = sg + 32 * TN;
+        s16x4 gl[NI], gh[NI], xl[CI], xh[CI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) w4_frag<TN>(sg, wn * (TN / 2) + a * 16, lane, gl[a], gh[a]);
+#pragma unroll
+        for (int b = 0; b < CI; ++b) w4_frag<TC>(sx, wc * (TC / 2) + b * 16, lane, xl[b], xh[b]);
+#pragma unroll
+        for (int a = 0; a < NI; a += 2) ring_fence4(gl[a], gh[a], gl[a + 1], gh[a + 1]);
+#pragma unroll
+        for (int b = 0; b < CI; b += 2) ring_fence4(xl[b], xh[b], xl[b + 1], xh[b + 1]);
+        bf16x8 gf[NI], xf[CI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) gf[a] = ring_join(gl[a], gh[a]);
+#pragma unroll
+        for (int b = 0; b < CI; ++b) xf[b] = ring_join(xl[b], xh[b]);
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < CI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int a = 0; a < NI; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], ones, accb[a], 0, 0, 0);
+        }
+    }
+    w4_wait_vm<0>();                                     // the run-ahead zero tiles must have landed before the LDS is released
+    float* dst = p.part + (size_t)zslice * p.N * p.Cin;
+#pragma unroll
+    for (int a = 0; a < NI; ++a) {
+        const int n = n0 + wn * (TN / 2) + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int b = 0; b < CI; ++b) {
+            const int c = c0 + wc * (TC / 2) + b * 16 + (lane & 15);
+            if (c < p.Cin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) dst[(size_t)(n + r) * p.Cin + c] = acc[a][b][r];
+            }
+        }
+        if (do_bias && (lane & 15) == 0) {               // every column of the ones product holds the column sums of G
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) p.bias_part[(size_t)zslice * p.N + n + r] = accb[a][r];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256, 2) k_wgrad4_3x3(WgradArgs p) {
+    constexpr int W = 64, ST = 4, XR = 256;                                   // tile width, G stages, X ring rows
+    __shared__ __attribute__((aligned(1024))) uint16_t sG[ST * 32 * W];       // 16 KB
+    __shared__ __attribute__((aligned(1024))) uint16_t sX[XR * W];            // 32 KB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int xcd = blockIdx.x & 7, k_in = blockIdx.x >> 3;
+    const int zslice = xcd + 8 * (k_in / p.ntiles3), tile3 = k_in % p.ntiles3;
+    if (zslice >= p.nslices3) return;
+    const int ntile = tile3 / p.ctiles, ctile = tile3 - ntile * p.ctiles;
+    const int n0 = ntile * W, c0 = ctile * W;
+    const int PW = p.Ws + 2, PH = p.Hs + 2, PP = PH * PW;
+    const int B = p.M / (p.Hs * p.Ws), MP = B * PP;                          // stride 1, pad 1: Ho = Hs, Wo = Ws
+    const int p_begin = zslice * p.m_per_slice;                              // multiple of 32
+    const int p_end = min(MP, p_begin + p.m_per_slice);
+    const int nsteps = (max(p_end - p_begin, 0) + 31) / 32;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.g), 0, 0x7ffffff0, 0x00020000);
+    // DMA roles: 8 rows per 1 KiB piece, piece `wave` of every 32-row block; lane -> (row in piece, physical chunk).  The padded pixel
+    // of the lane's row is carried as (b, py, px) and advanced by 32 per block.
+    const int prow = 8 * wave + (lane >> 3);
+    struct Pix { int b, py, px; };
+    auto split = [&](int q) {                     // q >= -PP
+        Pix r;
+        const int qq = q + PP;
+        r.b = qq / PP - 1;
+        const int rem = qq - (r.b + 1) * PP;
+        r.py = rem / PW;
+        r.px = rem - r.py * PW;
+        return r;
+    };
+    auto advance = [&](Pix& r) {
+        r.px += 32;
+        while (r.px >= PW) {
+            r.px -= PW;
+            if (++r.py == PH) {
+                r.py = 0;
+                ++r.b;
+            }
+        }
+    };
+    auto interior = [&](const Pix& r) { return r.b >= 0 && r.b < B && r.py >= 1 && r.py <= p.Hs && r.px >= 1 && r.px <= p.Ws; };
+    Pix gp = split(p_begin + prow);
+    int gq = p_begin + prow;                                                  // padded pixel of the lane's G row
+    const int gcolumn = n0 + (((lane & 7) ^ w4_swz<W>(prow)) << 3);
+    const bool gcol = gcolumn < p.N;
+    int xq = p_begin - 64 + prow;                                             // X runs ahead: the buffer is filled from p_begin - 64
+    Pix xp = split(xq);
+    const int xcolumn = c0 + (((lane & 7) ^ w4_swz<W>(xq & (XR - 1))) << 3);  // (ring row bits 0, 1, 3 never change: +32 per block)
+    const bool xcol = xcolumn < p.Cin;
+    int g_issued = 0;
+    auto issue_x = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool ok = xcol && interior(xp);
+        const unsigned off = ok ? (unsigned)((((xp.b * p.Hs + xp.py - 1) * p.Ws + xp.px - 1) * p.Cin + xcolumn) * 2) : OOB_OFF;
+        const int base_row = (xq - (lane >> 3)) & (XR - 1);                   // wave-uniform: first ring row of this piece
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, W4_LDS(sX + base_row * W), 16, off, 0, 0, 0);
+        xq += 32;
+        advance(xp);
+#endif
+    };
+    auto issue_g = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const bool ok = gcol && gq < p_end && interior(gp);
+        const unsigned off = ok ? (unsigned)((((gp.b * p.Hs + gp.py - 1) * p.Ws + gp.px - 1) * p.N + gcolumn) * 2) : OOB_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, W4_LDS(sG + (g_issued & (ST - 1)) * 32 * W + 8 * wave * W), 16, off, 0, 0, 0);
+        ++g_issued;
+        gq += 32;
+        advance(gp);
+#endif
+    };
+    // fragment addresses of the nine taps (bytes inside sX), advanced by 32 rows = 4 096 bytes per step (swizzle bits unchanged)
+    const int g4 = lane >> 4, i4 = lane & 15, q4 = i4 >> 2, pq4 = i4 & 3;
+    int alo[9], ahi[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int r0 = p_begin + (t / 3 - 1) * PW + (t % 3 - 1) + 8 * g4 + q4 + XR;          // >= 0: p_begin >= 0, halo < 256
+        alo[t] = 2 * w4_elem<W>(r0 & (XR - 1), 16 * wave, pq4);
+        ahi[t] = 2 * w4_elem<W>((r0 + 4) & (XR - 1), 16 * wave, pq4);
+    }
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int a = 0; a < 4; ++a) acc[t][a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // prologue: X blocks p_begin - 64 .. p_begin + 63, then three (G, X) steps in flight
+    issue_x();
+    issue_x();
+    issue_x();
+    issue_x();
+#pragma unroll
+    for (int j = 0; j < ST - 1; ++j) {
+        issue_g();
+        issue_x();
+    }
+    const char* sXb = reinterpret_cast<const char*>(sX);
+    for (int s = 0; s < nsteps; ++s) {
+        w4_wait_vm<(ST - 2) * 2>();          // landed: G of step s and X up to p0 + 95 (taps reach p0 + 31 + PW + 1 <= p0 + 82)
+        __builtin_amdgcn_s_barrier();        // everyone is done with step s - 1: its G stage and the X rows below p0 - 64 may be overwritten
+        issue_g();
+        issue_x();
+        const uint16_t* sg = sG + (s & (ST - 1)) * 32 * W;
+        // three groups of reads (G + taps 0..1 | taps 2..5 | taps 6..8); each group is in flight under the previous group's MFMAs
+        s16x4 gl[4], gh[4], xl[9], xh[9];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) w4_frag<W>(sg, a * 16, lane, gl[a], gh[a]);
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            if (t == 2) {
+                ring_fence(gl[0], gh[0], gl[1], gh[1], gl[2], gh[2], gl[3], gh[3]);
+                ring_fence4(xl[0], xh[0], xl[1], xh[1]);
+            }
+            if (t == 6) ring_fence(xl[2], xh[2], xl[3], xh[3], xl[4], xh[4], xl[5], xh[5]);
+            xl[t] = ring_tr(reinterpret_cast<const uint16_t*>(sXb + alo[t]));
+            xh[t] = ring_tr(reinterpret_cast<const uint16_t*>(sXb + ahi[t]));
+            alo[t] = (alo[t] + 32 * W * 2) & (XR * W * 2 - 1);
+            ahi[t] = (ahi[t] + 32 * W * 2) & (XR * W * 2 - 1);
+            if (t == 5 || t == 8) {        // MFMAs of the group fenced before this one was issued
+                const int t0 = (t == 5) ? 0 : 2, t1 = (t == 5) ? 2 : 6;
+#pragma unroll
+                for (int u = t0; u < t1; ++u) {
+                    const bf16x8 xf = ring_join(xl[u], xh[u]);
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+                        acc[u][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring_join(gl[a], gh[a]), xf, acc[u][a], 0, 0, 0);
+                }
+            }
+        }
+        ring_fence4(xl[6], xh[6], xl[7], xh[7]);
+        asm volatile("" : "+v"(xl[8]), "+v"(xh[8]));       // (the fence above waited for all of them; this pins tap 8 behind it)
+#pragma unroll
+        for (int u = 6; u < 9; ++u) {
+            const bf16x8 xf = ring_join(xl[u], xh[u]);
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[u][a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ring_join(gl[a], gh[a]), xf, acc[u][a], 0, 0, 0);
+        }
+    }
+    w4_wait_vm<0>();
+    float* dst = p.part + (size_t)zslice * p.N * 9 * p.Cin;
+    const int c = c0 + 16 * wave + (lane & 15);
+    if (c < p.Cin) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int n = n0 + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) dst[((size_t)(n + r) * 9 + t) * p.Cin + c] = acc[t][a][r];
+            }
+    }
+}
+// which weight gradients the streaming kernels take: flags bit 0 = a_rowmap, 1 = g_rowmap, 2 = g_scale
+static inline int wgrad4_kind(int N, int Cin, int ksize, int stride, int Ws, int flags) {
+    static const int on = getenv("PK_WGRAD4") ? atoi(getenv("PK_WGRAD4")) : 3;      // bit 0: single tap, bit 1: 3x3
+    if (flags) return 0;
+    if (ksize == 1 && stride == 1) return (on & 1) ? 1 : 0;
+    if (ksize == 3 && stride == 1 && Ws >= 1 && Ws <= 48 && !wgrad_wide(N, Cin, 9)) return (on & 2) ? 2 : 0;
+    return 0;
 }
 
 // out[...] = sum_s part[s][n][t][c]; layout 0: [N][T][Cin]; layout 1: OIHW = [N][Cin][T] (reference conv weight layout).
@@ -1048,10 +1396,11 @@ static inline void wgrad_tile2(int N, int Cin, int T, int& tn, int& tc) {
     if (N >= 128 && Cin >= 128) tn = tc = 128;
     else tn = tc = 64;
 }
-extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
+static int wgrad_slices_old(int M, int N, int Cin, int T) {
     // enough workgroups to fill 256 CUs several times over (>= 2048), but no slice shorter than 256 rows
     static const int target = getenv("PK_WGRAD_WGS") ? atoi(getenv("PK_WGRAD_WGS")) : 2048;
-    // (shorter slices for the low-resolution branches were measured: 64-row slices cost +1.3 ms per step in slab traffic)
+    // (shorter slices for the low-resolution branches were measured: 64-row slices cost +1.3 ms per step in slab traffic; longer ones
+    // are slower as well -- 512 / 1 024 rows: +0.35 / +1.8 ms per step -- each k_wgrad2 workgroup is bound by its own load latency)
     static const int min_rows = getenv("PK_WGRAD_ROWS") ? atoi(getenv("PK_WGRAD_ROWS")) : 256;
     if (wgrad_wide(N, Cin, T)) {
         // one 512-thread workgroup per CU (128 KB LDS ring): ~one round of equal-sized workgroups over the 256 CUs, in whole groups of
@@ -1074,6 +1423,30 @@ extern "C" int pk_wgrad_slices(int M, int N, int Cin, int T) {
     if (s > 512) s = 512;
     return s;
 }
+static inline void wgrad4_tile(int N, int Cin, int kind, int& tn, int& tc) {
+    tn = (kind == 2 || N <= 64) ? 64 : 128;
+    tc = (kind == 2 || Cin <= 64) ? 64 : 128;
+}
+// padded-pixel count of the 3x3 form (the K range of k_wgrad4_3x3); M = B * Hs * Ws
+static inline int wgrad4_rows(int M, int Hs, int Ws, int kind) { return kind == 2 ? (M / (Hs * Ws)) * (Hs + 2) * (Ws + 2) : M; }
+static int wgrad4_slices(int rows, int N, int Cin, int kind) {
+    // two workgroups per CU (single tap) / one (3x3: nine accumulator sets), slices of >= 256 rows (512 and 1 024 measured: within noise)
+    static const int t1 = getenv("PK_WGRAD4_WGS") ? atoi(getenv("PK_WGRAD4_WGS")) : 512;
+    static const int t9 = getenv("PK_WGRAD4_WGS9") ? atoi(getenv("PK_WGRAD4_WGS9")) : 256;
+    static const int min_rows = getenv("PK_WGRAD4_ROWS") ? atoi(getenv("PK_WGRAD4_ROWS")) : 256;
+    int tn, tc;
+    wgrad4_tile(N, Cin, kind, tn, tc);
+    const int tiles = ((N + tn - 1) / tn) * ((Cin + tc - 1) / tc);
+    int s = ((kind == 2 ? t9 : t1) + tiles - 1) / tiles;
+    const int max_s = (rows + min_rows - 1) / min_rows;
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
+extern "C" int pk_wgrad_slices(int M, int N, int Cin, int ksize, int stride, int Hs, int Ws, int flags) {
+    const int kind = wgrad4_kind(N, Cin, ksize, stride, Ws, flags);
+    if (kind) return wgrad4_slices(wgrad4_rows(M, Hs, Ws, kind), N, Cin, kind);
+    return wgrad_slices_old(M, N, Cin, ksize * ksize);
+}
 
 extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, float* dbias, int n_bias,
                              const int32_t* a_rowmap, const int32_t* g_rowmap, const float* g_scale, int g_rows_per_sample, int M,
@@ -1090,7 +1463,8 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     a.x = (const uint16_t*)x; a.g = (const uint16_t*)grad_out; a.part = workspace; a.a_rowmap = a_rowmap; a.g_rowmap = g_rowmap;
     a.g_scale = g_scale; a.g_rows_per_sample = g_rows_per_sample > 0 ? g_rows_per_sample : 1;
     a.M = M; a.N = N; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = ksize / 2;
-    const int S = pk_wgrad_slices(M, N, Cin, a.T);
+    const int kind4 = wgrad4_kind(N, Cin, ksize, stride, Ws, (a_rowmap ? 1 : 0) | (g_rowmap ? 2 : 0) | (g_scale ? 4 : 0));
+    const int S = pk_wgrad_slices(M, N, Cin, ksize, stride, Hs, Ws, (a_rowmap ? 1 : 0) | (g_rowmap ? 2 : 0) | (g_scale ? 4 : 0));
     PK_REQUIRE(n_bias >= 0 && n_bias <= N && (!dbias || n_bias > 0), "pk_wgrad_bf16: n_bias");
     a.bias_part = n_bias > 0 ? workspace + (size_t)S * N * a.T * Cin : nullptr;     // bias slabs follow the weight slabs
     a.m_per_slice = ((M + S - 1) / S + 63) / 64 * 64;
@@ -1099,7 +1473,24 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     a.ctiles = (Cin + tc - 1) / tc;
     hipStream_t st = (hipStream_t)stream;
     PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
-    if (wgrad_wide(N, Cin, a.T)) {
+    if (kind4) {
+        PK_SUPPORTED(kind4 == 1 || n_bias == 0, "pk_wgrad_bf16: the 3x3 streaming kernel has no bias-gradient path (convolutions here carry no bias)");
+        PK_REQUIRE(linear || (Ho == Hs && Wo == Ws), "pk_wgrad_bf16: stride-1 geometry");
+        int t4n, t4c;
+        wgrad4_tile(N, Cin, kind4, t4n, t4c);
+        const int rows = wgrad4_rows(M, Hs, Ws, kind4);
+        PK_REQUIRE((int64_t)rows * 2 < 0x3fffffffLL, "pk_wgrad_bf16: too many rows");
+        a.ctiles = (Cin + t4c - 1) / t4c;
+        a.ntiles3 = ((N + t4n - 1) / t4n) * a.ctiles;
+        a.nslices3 = S;
+        a.m_per_slice = ((rows + S - 1) / S + 31) / 32 * 32;
+        const dim3 grid(8 * ((S + 7) / 8) * a.ntiles3);
+        if (kind4 == 2) hipLaunchKernelGGL(k_wgrad4_3x3, grid, dim3(256), 0, st, a);
+        else if (t4n == 64 && t4c == 64) hipLaunchKernelGGL((k_wgrad4<64, 64>), grid, dim3(256), 0, st, a);
+        else if (t4n == 64) hipLaunchKernelGGL((k_wgrad4<64, 128>), grid, dim3(256), 0, st, a);
+        else if (t4c == 64) hipLaunchKernelGGL((k_wgrad4<128, 64>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((k_wgrad4<128, 128>), grid, dim3(256), 0, st, a);
+    } else if (wgrad_wide(N, Cin, a.T)) {
         PK_SUPPORTED(!linear && n_bias == 0, "pk_wgrad_bf16: the wide 3x3 kernel has no bias-gradient path (convolutions here carry no bias)");
         a.ctiles = Cin / 256;
         a.ntiles3 = (N / 256) * a.ctiles;

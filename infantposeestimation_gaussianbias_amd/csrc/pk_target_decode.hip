@@ -13,6 +13,14 @@ void pk_set_error(const char* fmt, ...) {
 }
 extern "C" const char* pk_last_error_string(void) { return g_err; }
 extern "C" int pk_version(void) { return 100; }
+// Profiling aid: an empty launch whose workgroup count is `id`, so a rocprofv3 kernel trace can be cut into program sections
+// (scripts/trace_sections.py); never launched unless POSE_MARKERS=1.
+__global__ void k_marker() {}
+extern "C" int pk_marker(int id, void* stream) {
+    PK_REQUIRE(id > 0 && id < 65536, "pk_marker: id out of range");
+    hipLaunchKernelGGL(k_marker, dim3(id), dim3(64), 0, (hipStream_t)stream);
+    return pk_launch_status("pk_marker");
+}
 
 // ================================================================================================ T1
 // One 256-thread workgroup per (b,k) map. Each thread redoes the (cheap) float64 index arithmetic, then the

@@ -157,6 +157,15 @@ def _order(src, dst):
         _EVENTS.clear()
 
 
+_MARK = os.environ.get("POSE_MARKERS", "0") == "1"           # profiling: section markers + branches serialised on one stream
+
+
+def _mark(i):
+    if _MARK:
+        from ._lib import call, stream_ptr
+        call("pk_marker", i, stream_ptr())
+
+
 class _Region(torch.autograd.Function):
     """fork -> fns[i](inputs_i) on stream i -> join, as one autograd node (see the section comment)."""
 
@@ -164,7 +173,7 @@ class _Region(torch.autograd.Function):
     def forward(ctx, fns, counts, *flat):
         cur = torch.cuda.current_stream()
         n = len(fns)
-        side = [cur] + [_side_stream(cur.device, i) for i in range(1, n)]
+        side = [cur] + [cur if _MARK else _side_stream(cur.device, i) for i in range(1, n)]
         for i in range(1, n):
             _order(cur, side[i])
         graphs, pos = [], 0
@@ -172,6 +181,7 @@ class _Region(torch.autograd.Function):
             ins = flat[pos:pos + counts[i]]
             pos += counts[i]
             with torch.cuda.stream(side[i]), torch.enable_grad():
+                _mark(100 + i)
                 loc = []
                 for t in ins:
                     if i:
@@ -185,6 +195,7 @@ class _Region(torch.autograd.Function):
             _order(side[i], cur)
             for t in graphs[i][1]:
                 t.record_stream(cur)
+        _mark(99)
         ctx.graphs, ctx.side = graphs, side
         first = {}
         ctx.same = [first.setdefault(id(t), k) for k, t in enumerate(flat)]     # index of the first occurrence of each input
@@ -203,6 +214,7 @@ class _Region(torch.autograd.Function):
             pos += len(outs)
             pairs = [(o, g) for o, g in zip(outs, gs) if g is not None and o.requires_grad]
             with torch.cuda.stream(side[i]):
+                _mark(200 + i)
                 if pairs:
                     if i:
                         for _, g in pairs:
@@ -217,6 +229,7 @@ class _Region(torch.autograd.Function):
                     t.grad = None
         for i in range(1, n):
             _order(side[i], cur)
+        _mark(199)
         ctx.graphs = None
         # An input shared by several callables (exchange unit: every output reads every branch) gets one gradient per use.
         # Sum them here in ONE launch per input instead of leaving 2-3 elementwise adds per input to the autograd engine.

@@ -335,8 +335,11 @@ class Trainer:
         self.sched = WarmupMultiStepLR(self.opt, t, iters_per_epoch)
         self.comm = GradientExchange(self.opt, bucket_mb, overlap=overlap_comm)
         self.comm.broadcast_initial_state()
+        self._ms_cb = None
         if self.comm.world > 1 and overlap_comm:
-            nnops.set_milestone_callback(self._milestone)
+            self._ms_cb = self._milestone
+        # (Measured and dropped for one GPU: running the postponed slab reductions of the finished stages on an auxiliary stream at
+        # the same milestones -- 20.29 -> 20.79 ms per step; the reduction competes with the backward kernels for HBM and queues.)
         # >= 2 eager steps before capture: step 1 installs the gradient sinks, step 2 builds the descriptor tables that depend on
         # them (deferred reductions, padded-twin extraction) -- table uploads are host->device copies and cannot be captured
         self.use_graph, self.graph_warmup = use_graph, max(2, graph_warmup)
@@ -368,7 +371,7 @@ class Trainer:
         out = self.model(x, batch["target"], batch["target_weight"], gt_keypoints=batch.get("keypoints"),
                          input_size=self.cfg.data.input_size)
         out["loss"].backward()
-        nnops.finalize_deferred()      # ONE launch: all postponed slab reductions of parameter gradients
+        nnops.finalize_deferred()      # ONE launch: all postponed slab reductions of parameter gradients (the rest of them after milestones)
         tw = getattr(self.model, "_pk_twin", None)
         if tw:
             tw.grads_to_real()         # padded twin: no-op when the end-of-backward callback already extracted the gradients
@@ -462,6 +465,7 @@ class Trainer:
         from . import dispatch
         dispatch.set_streams(self._want_streams)
         dispatch.set_region_mode(self._region)    # capturable fork/join (one autograd node per parallel region)
+        nnops.set_milestone_callback(self._ms_cb)  # process-wide hook: the trainer that steps owns it
         if not self.use_graph:
             return self._eager_step(batch)
         if self._graph is None:

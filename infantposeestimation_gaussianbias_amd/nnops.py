@@ -13,6 +13,8 @@ Channel counts must be multiples of 8 (16-byte bf16 chunks) and head_dim a multi
 (HRFormer-base C=78 / head_dim 39, HRNet-W18) run through an 8-aligned padded twin built from the same kernels
 (models/padded.py).  There is no PyTorch / CPU fallback and nothing here touches oracle/.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -308,6 +310,19 @@ def to_features(x_nchw_f32, cpad=8):
     return y
 
 
+_WGRAD_LOG = None
+if os.environ.get("POSE_LOG_WGRAD") == "1":          # profiling: the weight-gradient launch shapes of a run, printed at exit
+    import atexit
+    import collections
+    _WGRAD_LOG = collections.Counter()
+
+    def _dump_wgrad_log():
+        print("# weight-gradient launches: count x (M, N, Cin, ksize, stride, a_map, g_map, g_scale, n_bias, slices, deferred)")
+        for k, v in sorted(_WGRAD_LOG.items(), key=lambda kv: -kv[1] * kv[0][0] * (kv[0][1] + kv[0][2])):
+            print(f"# {v:4d} x {k}  slab MB {k[9] * k[1] * (k[3] ** 2 * k[2] + 1) * 4 / 1e6:.1f}")
+    atexit.register(_dump_wgrad_log)
+
+
 def _conv_geometry(x, ksize, stride):
     B, Hs, Ws, Cin = x.shape
     pad = ksize // 2
@@ -346,9 +361,12 @@ def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=No
     else:
         B, Hs, Ws, Ho, Wo = geom
         M = B * Ho * Wo
-    S = _lib.lib.pk_wgrad_slices(M, N, Cin, T)
+    flags = (1 if a_map is not None else 0) | (2 if g_map is not None else 0) | (4 if g_scale is not None else 0)
+    S = _lib.lib.pk_wgrad_slices(M, N, Cin, ksize, stride, Hs, Ws, flags)
     layout = 1 if (geom is not None and oihw) else 0
     n_bias = 0 if dbias is None else dbias.numel()
+    if _WGRAD_LOG is not None:
+        _WGRAD_LOG[(M, N, Cin, ksize, stride, a_map is not None, g_map is not None, g_scale is not None, n_bias, S, bool(deferred))] += 1
     if deferred and out is not None and deferral_enabled():
         # slabs into a persistent workspace, reduction postponed to finalize_deferred()
         ws = _workspace(out, "w", S * N * (T * Cin + 1))

@@ -49,6 +49,7 @@ def main(path, nsteps=3):
     ev.sort()
     live, last = set(), ev[0][0]
     alone, share, hist = collections.defaultdict(float), collections.defaultdict(float), collections.Counter()
+    alone_k = collections.defaultdict(float)
     for t, kind, k in ev:
         dt = (t - last) / 1e6 / nsteps
         if dt > 0:
@@ -58,12 +59,57 @@ def main(path, nsteps=3):
                 share[n] += dt / len(live)
                 if len(live) == 1:
                     alone[n] += dt
+                    alone_k[j] += dt
         last = t
         (live.add if kind else live.discard)(k)
     print("time by number of kernels in flight (ms/step): " + ", ".join(f"{k}: {v:.2f}" for k, v in sorted(hist.items())))
     print("kernel time when nothing else runs (alone) / fair share of wall time, top 25:")
     for n, v in sorted(share.items(), key=lambda kv: -kv[1])[:25]:
         print(f"{alone[n]:7.3f} ms alone {v:7.3f} ms share  {n}")
+    by_shape(seg, nsteps, alone_k)
+    per = len(seg) // nsteps
+    timeline(seg[len(seg) - 2 * per:len(seg) - per] if nsteps >= 2 else seg)
+
+
+def _wgs(r):
+    n = 1
+    for a in "XYZ":
+        n *= max(1, int(r.get("Grid_Size_" + a, 1)) // max(1, int(r.get("Workgroup_Size_" + a, 1))))
+    return n
+
+
+def by_shape(seg, nsteps, alone_of):
+    """Aggregate by (kernel, workgroups): the launch shapes inside one kernel family."""
+    tot, cnt = collections.defaultdict(float), collections.Counter()
+    for k, r in enumerate(seg):
+        key = r["Kernel_Name"].replace("void ", "")[:40] + f" [{_wgs(r)}]"
+        tot[key] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 / nsteps
+        cnt[key] += 1
+    print("by (kernel, workgroups), top 40 by alone time:  alone ms | total ms | launches x us")
+    al = collections.defaultdict(float)
+    for k, v in alone_of.items():
+        r = seg[k]
+        al[r["Kernel_Name"].replace("void ", "")[:40] + f" [{_wgs(r)}]"] += v
+    for key, v in sorted(al.items(), key=lambda kv: -kv[1])[:40]:
+        print(f"{v:7.3f} | {tot[key]:7.3f} | {cnt[key] / nsteps:5.0f} x {tot[key] / (cnt[key] / nsteps) * 1e3:7.1f}  {key}")
+
+
+def timeline(seg, bin_ms=0.5):
+    """One step as a sequence of `bin_ms` bins: mean number of kernels in flight and the kernels (name, workgroups) with most time."""
+    t0 = int(seg[0]["Start_Timestamp"])
+    nb = int((int(seg[-1]["End_Timestamp"]) - t0) / 1e6 / bin_ms) + 1
+    occ = [collections.defaultdict(float) for _ in range(nb)]
+    for r in seg:
+        s, e = (int(r["Start_Timestamp"]) - t0) / 1e6, (int(r["End_Timestamp"]) - t0) / 1e6
+        name = r["Kernel_Name"].replace("void ", "")[:34] + f" [{_wgs(r)}]"
+        b = int(s / bin_ms)
+        while b < nb and b * bin_ms < e:
+            occ[b][name] += min(e, (b + 1) * bin_ms) - max(s, b * bin_ms)
+            b += 1
+    print(f"timeline of the last step, {bin_ms} ms bins: mean kernels in flight | top kernels [workgroups] ms")
+    for b, o in enumerate(occ):
+        top = sorted(o.items(), key=lambda kv: -kv[1])[:3]
+        print(f"{b * bin_ms:5.1f} ms  {sum(o.values()) / bin_ms:4.2f} | " + "; ".join(f"{n} {v:.2f}" for n, v in top))
 
 
 if __name__ == "__main__":

@@ -319,6 +319,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     };
     const int frow = lane & 15, fkc = lane >> 4;
     auto compute = [&](int buf) {
+        // (Measured and dropped for the DMA tiles: fragment reads through inline assembly, as in the weight-gradient rings below, so
+        // that the compiler's `s_waitcnt vmcnt(0)` in front of the first ds_read -- it cannot prove that the tile requested a moment
+        // ago is a different LDS buffer -- disappears and a workgroup overlaps its own loads with its own MFMAs: head conv forward
+        // 293 -> 327 us, dgrad 264 -> 273 us.  With two workgroups per CU the other workgroup already covers the loads, and the
+        // hand-placed lgkmcnt(0) fences schedule worse than the compiler's counted waits.  The bound of this tiling is LDS read
+        // bandwidth: 12 fragment reads per 32 MFMAs and wave (16x16x32 tiles); a 32x32x16 tiling would halve it.)
         if constexpr (BN >= 128 && KS == 2 && FRAG_PREFETCH) {
             // All fragments of the staged tile are read up front into separate registers (KS x (NI + MI) x 4 VGPRs; the kernel
             // sits at 2 waves/SIMD either way) and the scheduler is told to interleave the second K-step's LDS reads with the
@@ -814,12 +820,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 
 //     transpose reads `ds_read_b64_tr_b16` of a 32-lane half (rows r..r+3 and r+8..r+11, 32 columns) then touch 32 distinct
 //     8-byte bank pairs (without it all rows alias: 8-way conflicts).
 // One workgroup per CU (128 KB of LDS), 1-D grid of 9 taps x S slices ~ one round of workgroups with equal work.
-// LDS reads of the DMA rings go through inline assembly.  The compiler cannot tell which LDS bytes an outstanding `buffer_load ...
-// lds` will write, so before any ds_read it can see it inserts `s_waitcnt vmcnt(0)` -- i.e. it drains the whole ring (including the
-// steps issued a moment ago) on every step and the loop runs at one memory round trip per step, however deep the ring is (this is
-// what held the first version of k_wgrad3 at 25 % of the MFMA peak).  The kernels below do their own accounting (counted vmcnt +
-// barrier before a stage is read), read through ring_tr(), and close each group of reads with ring_fence(), which waits for the LDS
-// data and, by naming the fragments as in/out operands, keeps the MFMAs behind it.
+// LDS reads of tiles that are filled by LDS-DMA go through inline assembly.  The compiler cannot tell which LDS bytes an outstanding
+// `buffer_load ... lds` will write, so before any ds_read it can see it inserts `s_waitcnt vmcnt(0)`: the tile requested a moment ago
+// is awaited BEFORE the current one is multiplied: a four-deep ring is drained on every step (first version of k_wgrad3: 25 % of
+// the MFMA peak, 372 us; 289 us with the reads below).  The kernels do their own accounting
+// (counted vmcnt / barrier before a stage is read), read through ring_tr(), and close each group of reads with a fence that waits
+// for the LDS data and, by naming the fragments as in/out operands, keeps the MFMAs behind it.
 __device__ __forceinline__ s16x4 ring_tr(const uint16_t* a) {
     s16x4 v;
     asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)a) : "memory");

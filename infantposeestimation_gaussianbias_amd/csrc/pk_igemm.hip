@@ -681,10 +681,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 
     __shared__ __attribute__((aligned(16))) uint16_t sG[2][MK * PN];
     __shared__ __attribute__((aligned(16))) uint16_t sX[2][MK * PC];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ntile = blockIdx.x / p.ctiles, ctile = blockIdx.x - ntile * p.ctiles;
-    const int n0 = ntile * TN, c0 = ctile * TC, t = blockIdx.y;
+    // 3x3: 1-D grid, the nine taps (and the output tiles) of one M-slice on ONE XCD (slice = xcd + 8 * group): they read the same
+    // rows of G and overlapping rows of X at about the same time, so eight of the nine reads are L2 hits.
+    int bx = blockIdx.x, t = blockIdx.y, bz = blockIdx.z;
+    if (p.nslices3 > 0) {
+        const int xcd = blockIdx.x & 7, k_in = blockIdx.x >> 3, per_slice = 9 * p.ntiles3;
+        bz = xcd + 8 * (k_in / per_slice);
+        if (bz >= p.nslices3) return;            // padding workgroups of the last group (whole workgroup, before any barrier)
+        const int rem = k_in % per_slice;
+        t = rem % 9;
+        bx = rem / 9;
+    }
+    const int ntile = bx / p.ctiles, ctile = bx - ntile * p.ctiles;
+    const int n0 = ntile * TN, c0 = ctile * TC;
     const int kw_n = (p.T == 9) ? 3 : 1, kh = t / kw_n, kw = t - kh * kw_n;
-    const int m_begin = blockIdx.z * p.m_per_slice;
+    const int m_begin = bz * p.m_per_slice;
     const int m_end = min(p.M, m_begin + p.m_per_slice);
     const bool linear = (p.Ho == 0);
     const int hw = p.Ho * p.Wo;
@@ -788,8 +799,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 
         if (s + 1 < nsteps) store(buf ^ 1);
         __syncthreads();
     }
-    if (do_bias && tid < TN && n0 + tid < p.N) p.bias_part[(size_t)blockIdx.z * p.N + n0 + tid] = bsum;
-    float* dst = p.part + (size_t)blockIdx.z * p.N * p.T * p.Cin;
+    if (do_bias && tid < TN && n0 + tid < p.N) p.bias_part[(size_t)bz * p.N + n0 + tid] = bsum;
+    float* dst = p.part + (size_t)bz * p.N * p.T * p.Cin;
 #pragma unroll
     for (int a = 0; a < NI; ++a)
 #pragma unroll
@@ -1007,7 +1018,12 @@ __device__ __forceinline__ void ring_fence4(s16x4& a, s16x4& b, s16x4& c, s16x4&
 template <int N> __device__ __forceinline__ void w4_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 #define W4_LDS(ptr) ((__attribute__((address_space(3))) void*)(ptr))
 
-template <int TN, int TC>
+// COLS = true ("column form", 3x3 convolutions the nine-tap kernel does not take: stride 2, or stride 1 on wide images): the X operand
+// is the im2col matrix [M output pixels][9 * Cin], never materialised -- the lane that stages 16-byte chunk j of a row fetches
+// tap j / (Cin / 8), channels 8 (j % (Cin / 8)) of that pixel's window (its own source address per DMA lane, zero outside the image),
+// and the output columns of the tile are the contiguous (tap, c) columns of dW[n][tap][c].  For the stem (Cin = 8: one chunk per tap)
+// all nine taps share one 128-column tile and one pass over G instead of nine.
+template <int TN, int TC, bool COLS = false>
 __global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
     constexpr int ST = (TN + TC <= 128) ? 8 : 4;                  // ring depth: 64 KB (64+64: 8 x 8 KB, 128+128: 4 x 16 KB), 48 KB otherwise
     constexpr int PG = TN / 64, PX = TC / 64, PER = PG + PX;      // 1 KiB DMA pieces per wave and step
@@ -1028,9 +1044,11 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
     const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.g), 0, 0x7ffffff0, 0x00020000);
     // this wave's pieces: G pieces wave + 4 j (j < PG), X pieces wave + 4 j (j < PX); lane -> (row in piece, physical chunk)
+    const int ncols = COLS ? 9 * p.Cin : p.Cin;                      // columns of the X operand = row length of one output row
     int gm[PG], xm[PX];
     unsigned goff[PG], xoff[PX];
     bool gcol[PG], xcol[PX];
+    int xb[PX], xoy[PX], xox[PX], xkh[PX], xkw[PX], xch[PX];         // column form: pixel of the lane's row (carried), its tap and channel
 #pragma unroll
     for (int j = 0; j < PG; ++j) {
         const int row = (wave + 4 * j) * RG + lane / (TN / 8);
@@ -1044,8 +1062,18 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
         const int row = (wave + 4 * j) * RX + lane / (TC / 8);
         const int col = c0 + (((lane % (TC / 8)) ^ w4_swz<TC>(row)) << 3);
         xm[j] = m_begin + row;
-        xcol[j] = col < p.Cin;
+        xcol[j] = col < ncols;
         xoff[j] = (unsigned)((xm[j] * p.Cin + col) * 2);
+        if (COLS) {
+            const int tap = col / p.Cin, hw = p.Ho * p.Wo;
+            xch[j] = col - tap * p.Cin;
+            xkh[j] = tap / 3 - p.pad;
+            xkw[j] = tap % 3 - p.pad;
+            xb[j] = xm[j] / hw;
+            const int r = xm[j] - xb[j] * hw;
+            xoy[j] = r / p.Wo;
+            xox[j] = r - xoy[j] * p.Wo;
+        }
     }
     const unsigned gstep = (unsigned)(64 * p.N), xstep = (unsigned)(64 * p.Cin);       // bytes per 32 rows
     int issued = 0;
@@ -1062,7 +1090,21 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
         }
 #pragma unroll
         for (int j = 0; j < PX; ++j) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, W4_LDS(sx + (wave + 4 * j) * 512), 16, (xcol[j] && xm[j] < m_end) ? xoff[j] : OOB_OFF, 0, 0, 0);
+            unsigned off = (xcol[j] && xm[j] < m_end) ? xoff[j] : OOB_OFF;
+            if (COLS) {
+                const int iy = xoy[j] * p.stride + xkh[j], ix = xox[j] * p.stride + xkw[j];
+                const bool in = xcol[j] && xm[j] < m_end && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+                off = in ? (unsigned)((((xb[j] * p.Hs + iy) * p.Ws + ix) * p.Cin + xch[j]) * 2) : OOB_OFF;
+                xox[j] += 32;                                 // next step: 32 output pixels further, with carries
+                while (xox[j] >= p.Wo) {
+                    xox[j] -= p.Wo;
+                    if (++xoy[j] == p.Ho) {
+                        xoy[j] = 0;
+                        ++xb[j];
+                    }
+                }
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, W4_LDS(sx + (wave + 4 * j) * 512), 16, off, 0, 0, 0);
             xm[j] += 32;
             xoff[j] += xstep;
         }
@@ -1109,17 +1151,17 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
         }
     }
     w4_wait_vm<0>();                                     // the run-ahead zero tiles must have landed before the LDS is released
-    float* dst = p.part + (size_t)zslice * p.N * p.Cin;
+    float* dst = p.part + (size_t)zslice * p.N * ncols;
 #pragma unroll
     for (int a = 0; a < NI; ++a) {
         const int n = n0 + wn * (TN / 2) + a * 16 + (lane >> 4) * 4;
 #pragma unroll
         for (int b = 0; b < CI; ++b) {
             const int c = c0 + wc * (TC / 2) + b * 16 + (lane & 15);
-            if (c < p.Cin) {
+            if (c < ncols) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    if (n + r < p.N) dst[(size_t)(n + r) * p.Cin + c] = acc[a][b][r];
+                    if (n + r < p.N) dst[(size_t)(n + r) * ncols + c] = acc[a][b][r];
             }
         }
         if (do_bias && (lane & 15) == 0) {               // every column of the ones product holds the column sums of G
@@ -1283,10 +1325,12 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4_3x3(WgradArgs p) {
 }
 // which weight gradients the streaming kernels take: flags bit 0 = a_rowmap, 1 = g_rowmap, 2 = g_scale
 static inline int wgrad4_kind(int N, int Cin, int ksize, int stride, int Ws, int flags) {
-    static const int on = getenv("PK_WGRAD4") ? atoi(getenv("PK_WGRAD4")) : 3;      // bit 0: single tap, bit 1: 3x3
+    static const int on = getenv("PK_WGRAD4") ? atoi(getenv("PK_WGRAD4")) : 7;      // bit 0: single tap, bit 1: nine-tap 3x3, bit 2: column-form 3x3
     if (flags) return 0;
     if (ksize == 1 && stride == 1) return (on & 1) ? 1 : 0;
-    if (ksize == 3 && stride == 1 && Ws >= 1 && Ws <= 48 && !wgrad_wide(N, Cin, 9)) return (on & 2) ? 2 : 0;
+    if (ksize == 3 && wgrad_wide(N, Cin, 9)) return 0;
+    if (ksize == 3 && stride == 1 && Ws >= 1 && Ws <= 48) return (on & 2) ? 2 : 0;
+    if (ksize == 3) return (on & 4) ? 3 : 0;
     return 0;
 }
 
@@ -1431,7 +1475,7 @@ static int wgrad_slices_old(int M, int N, int Cin, int T) {
 }
 static inline void wgrad4_tile(int N, int Cin, int kind, int& tn, int& tc) {
     tn = (kind == 2 || N <= 64) ? 64 : 128;
-    tc = (kind == 2 || Cin <= 64) ? 64 : 128;
+    tc = (kind == 2 || (kind == 1 && Cin <= 64)) ? 64 : 128;         // column form: 9 * Cin >= 72 columns
 }
 // padded-pixel count of the 3x3 form (the K range of k_wgrad4_3x3); M = B * Hs * Ws
 static inline int wgrad4_rows(int M, int Hs, int Ws, int kind) { return kind == 2 ? (M / (Hs * Ws)) * (Hs + 2) * (Ws + 2) : M; }
@@ -1442,7 +1486,7 @@ static int wgrad4_slices(int rows, int N, int Cin, int kind) {
     static const int min_rows = getenv("PK_WGRAD4_ROWS") ? atoi(getenv("PK_WGRAD4_ROWS")) : 256;
     int tn, tc;
     wgrad4_tile(N, Cin, kind, tn, tc);
-    const int tiles = ((N + tn - 1) / tn) * ((Cin + tc - 1) / tc);
+    const int tiles = ((N + tn - 1) / tn) * (((kind == 3 ? 9 * Cin : Cin) + tc - 1) / tc);
     int s = ((kind == 2 ? t9 : t1) + tiles - 1) / tiles;
     const int max_s = (rows + min_rows - 1) / min_rows;
     if (s > max_s) s = max_s;
@@ -1481,17 +1525,19 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
     if (kind4) {
         PK_SUPPORTED(kind4 == 1 || n_bias == 0, "pk_wgrad_bf16: the 3x3 streaming kernel has no bias-gradient path (convolutions here carry no bias)");
-        PK_REQUIRE(linear || (Ho == Hs && Wo == Ws), "pk_wgrad_bf16: stride-1 geometry");
+        PK_REQUIRE(linear || kind4 == 3 || (Ho == Hs && Wo == Ws), "pk_wgrad_bf16: stride-1 geometry");
         int t4n, t4c;
         wgrad4_tile(N, Cin, kind4, t4n, t4c);
         const int rows = wgrad4_rows(M, Hs, Ws, kind4);
         PK_REQUIRE((int64_t)rows * 2 < 0x3fffffffLL, "pk_wgrad_bf16: too many rows");
-        a.ctiles = (Cin + t4c - 1) / t4c;
+        a.ctiles = ((kind4 == 3 ? 9 * Cin : Cin) + t4c - 1) / t4c;
         a.ntiles3 = ((N + t4n - 1) / t4n) * a.ctiles;
         a.nslices3 = S;
         a.m_per_slice = ((rows + S - 1) / S + 31) / 32 * 32;
         const dim3 grid(8 * ((S + 7) / 8) * a.ntiles3);
         if (kind4 == 2) hipLaunchKernelGGL(k_wgrad4_3x3, grid, dim3(256), 0, st, a);
+        else if (kind4 == 3 && t4n == 64) hipLaunchKernelGGL((k_wgrad4<64, 128, true>), grid, dim3(256), 0, st, a);
+        else if (kind4 == 3) hipLaunchKernelGGL((k_wgrad4<128, 128, true>), grid, dim3(256), 0, st, a);
         else if (t4n == 64 && t4c == 64) hipLaunchKernelGGL((k_wgrad4<64, 64>), grid, dim3(256), 0, st, a);
         else if (t4n == 64) hipLaunchKernelGGL((k_wgrad4<64, 128>), grid, dim3(256), 0, st, a);
         else if (t4c == 64) hipLaunchKernelGGL((k_wgrad4<128, 64>), grid, dim3(256), 0, st, a);
@@ -1510,7 +1556,13 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
         }
         hipLaunchKernelGGL(k_wgrad3, dim3(8 * ((S + 7) / 8) * 9 * a.ntiles3), dim3(512), W3_LDS, st, a);
     } else {
-        const dim3 grid(((N + tn - 1) / tn) * a.ctiles, a.T, S);
+        dim3 grid(((N + tn - 1) / tn) * a.ctiles, a.T, S);
+        static const int xcd9 = getenv("PK_WGRAD2_XCD") ? atoi(getenv("PK_WGRAD2_XCD")) : 1;
+        if (a.T == 9 && xcd9) {
+            a.ntiles3 = grid.x;
+            a.nslices3 = S;
+            grid = dim3(8 * ((S + 7) / 8) * 9 * a.ntiles3);
+        }
         if (tn == 128) hipLaunchKernelGGL((k_wgrad2<128, 128, 32>), grid, dim3(256), 0, st, a);
         else hipLaunchKernelGGL((k_wgrad2<64, 64, 32>), grid, dim3(256), 0, st, a);
     }

@@ -1,8 +1,7 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
-timeout -k 10 500 python -m pytest tests/test_gpu_network_ops.py -m gpu -q -x --timeout 200 > gpurun_out/t_w4.log 2>&1; rc=$?
-tail -2 gpurun_out/t_w4.log | cut -c1-250
-if [ $rc -ne 0 ]; then grep -n "^E  \|^FAILED" gpurun_out/t_w4.log | head -20; exit $rc; fi
-for v in 3 7 3 7; do PK_WGRAD4=$v timeout -k 10 300 python bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-roofline 2>gpurun_out/w4.err | grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' | tr '\n' ' '; echo " PK_WGRAD4=$v"; done
-PK_WGRAD4=7 timeout -k 10 300 python scripts/bench_kernels.py "s2" 2>&1 | grep wgrad | cut -c1-150
+timeout -k 10 400 python bench.py --config hrformer_base_infer --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_base_r02.json 2> gpurun_out/bench_base_r02.err || { tail -5 gpurun_out/bench_base_r02.err; exit 1; }
+cat gpurun_out/bench_base_r02.json | cut -c1-700; grep -i "capture\|graph" gpurun_out/bench_base_r02.err | head -5
+timeout -k 10 400 python bench.py --config hrnet_w32_384 --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_w32_r02.json 2> gpurun_out/bench_w32_r02.err || { tail -5 gpurun_out/bench_w32_r02.err; exit 1; }
+cat gpurun_out/bench_w32_r02.json | cut -c1-700

@@ -46,11 +46,31 @@ CONFIGS = {
 
 
 def time_kernel(fn, iters=20, warmup=3):
-    """Average device time of `fn()` (one launch sequence on torch's current stream == the stream the C-ABI launches on)."""
+    """Average device time of `fn()` (one launch sequence on torch's current stream == the stream the C-ABI launches on).  The
+    `iters` calls are captured into one hipGraph and the replay is timed with HIP events: launched one by one from Python, kernels
+    shorter than ~20 us are paced by the host (two C-ABI calls take longer to issue than a 12 us kernel takes to run)."""
     for _ in range(warmup):
         fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    try:
+        g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                for _ in range(iters):
+                    fn()
+        torch.cuda.current_stream().wait_stream(side)
+        g.replay()
+        torch.cuda.synchronize()
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / iters * 1e-3
+    except Exception as e:       # noqa: BLE001  (a refused capture falls back to host-paced launches)
+        log(f"time_kernel: graph capture refused ({type(e).__name__}: {e}); timing host-paced launches")
+        torch.cuda.synchronize()
     e0.record()
     for _ in range(iters):
         fn()
@@ -76,7 +96,7 @@ def _entry(kernel, what, bound, sec, flops=None, bytes_=None, traffic=None, laun
 
 
 def roofline_table(model, B):
-    """The top aggregate kernels of the step (profiles/r02_trace_summary_*.txt), each on its dominant shape, timed live here.
+    """The top aggregate kernels of the step (profiles/r02_trace_summary.txt), each on its dominant shape, timed live here.
     Algorithmic work: GEMM-shaped kernels 2*M*N*K flops vs the dense bf16 MFMA peak; the shallow token GEMMs and the
     fused block kernels are HBM-bound: bytes = every operand read once + every result written once."""
     from infantposeestimation_gaussianbias_amd import _lib, nnops
@@ -103,16 +123,32 @@ def roofline_table(model, B):
         sec = time_kernel(lambda: nnops._conv_raw(x, wf, conv.weight.shape[0], 3, 1, True))
         out.append(_entry("k_igemm2<256,128,2,2,32>", "head conv3x3 256->256 @64x48, fwd + BN-stat epilogue", "mfma", sec, flops=flops,
                           bytes_=2.0 * (2 * M * C) + 2 * 9 * C * C, traffic=traffic, launches=8))
-        # 2. its weight gradient: k_wgrad2<128,128,32> (5 launches per step on the head's 3x3 convs)
-        sec = time_kernel(lambda: nnops._wgrad(x, g, C, C, 3, 1, (B, H, W, H, W)))
-        out.append(_entry("k_wgrad2<128,128,32> (+ slab reduce)", "head conv3x3 256->256 @64x48 weight gradient", "mfma", sec, flops=flops,
-                          bytes_=2.0 * (2 * M * C), launches=73))
-        # 3. k_wgrad2<64,64,32>: dominant shape = qkv weight gradient of the branch-0 blocks (tokens x 96 x 32)
+        # Weight gradients as the step launches them: slabs only (dw = NULL), the split-M partial sums of ALL layers are reduced by
+        # the step's one k_reduce_many launch.
+        def wgrad_slabs(xx, gg, Mr, N_, Cin_, ks, geom, a_map=None):
+            Bq, Hq, Wq = geom if geom else (0, 0, 0)
+            S = _lib.lib.pk_wgrad_slices(Mr, N_, Cin_, ks, 1, Hq, Wq, 1 if a_map is not None else 0)
+            ws = torch.empty(S * N_ * (ks * ks * Cin_ + 1), device=dev)
+            return lambda: call("pk_wgrad_bf16", xx, gg, ws, None, None, 0, a_map, None, None, 0, Mr, N_, Cin_, ks, 1, Bq, Hq, Wq, Hq, Wq, 0,
+                                stream_ptr())
+        # 2. the head conv's weight gradient: k_wgrad3 (256 x 256 tile, 4-stage LDS-DMA ring), 3 launches per step
+        sec = time_kernel(wgrad_slabs(x, g, M, C, C, 3, (B, H, W)))
+        out.append(_entry("k_wgrad3", "head conv3x3 256->256 @64x48 weight gradient (slabs)", "mfma", sec, flops=flops,
+                          bytes_=2.0 * (2 * M * C), launches=3))
+        # 3. streaming weight gradient k_wgrad4<128,64>: qkv weight gradient of the branch-0 blocks (tokens x 96 x 32)
         Mw = B * 70 * 49
         u, dq = torch.randn(Mw, 32, device=dev).to(BF), torch.randn(Mw, 96, device=dev).to(BF)
-        sec = time_kernel(lambda: nnops._wgrad(u, dq, 96, 32, 1, 1, None, M=Mw))
-        out.append(_entry("k_wgrad2<64,64,32> (+ slab reduce)", "qkv weight gradient, branch 0: 219520 tokens x 96 x 32", "hbm", sec,
-                          flops=2.0 * Mw * 96 * 32, bytes_=2.0 * Mw * (96 + 32), launches=130))
+        sec = time_kernel(wgrad_slabs(u, dq, Mw, 96, 32, 1, None))
+        out.append(_entry("k_wgrad4<128,64>", "qkv weight gradient, branch 0: 219520 tokens x 96 x 32 (slabs)", "hbm", sec,
+                          flops=2.0 * Mw * 96 * 32, bytes_=2.0 * Mw * (96 + 32), launches=14))
+        # 3b. k_wgrad2<64,64,32> (81 launches: the weight gradients that still take a window row map or a DropPath row scale):
+        # dominant shape = qkv weight gradient of the branch-1 blocks, x gathered through the window map
+        amap1, nwin1 = nnops.window_rowmap(B, 32, 24, dev)
+        Mw1 = amap1.numel()
+        u1, dq1 = torch.randn(B * 32 * 24, 64, device=dev).to(BF), torch.randn(Mw1, 192, device=dev).to(BF)
+        sec = time_kernel(wgrad_slabs(u1, dq1, Mw1, 192, 64, 1, None, a_map=amap1))
+        out.append(_entry("k_wgrad2<64,64,32>", f"qkv weight gradient, branch 1: {Mw1} window tokens x 192 x 64, gathered rows (slabs)", "hbm",
+                          sec, flops=2.0 * Mw1 * 192 * 64, bytes_=2.0 * (Mw1 * 192 + B * 32 * 24 * 64), launches=81))
         # 4. k_igemm2<128,64,4,1,64>: dominant shape = 3x3 conv 64->64 @64x48 (layer1 / transition convs), forward with BN statistics
         x64 = torch.randn(B, H, W, 64, device=dev).to(BF)
         w64 = torch.randn(64, 9, 64, device=dev).to(BF)

@@ -1,7 +1,6 @@
 #!/bin/bash
 set -o pipefail
 cd "$GRAFT_REPO_ROOT"
-timeout -k 10 400 python bench.py --config hrformer_base_infer --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_base_r02.json 2> gpurun_out/bench_base_r02.err || { tail -5 gpurun_out/bench_base_r02.err; exit 1; }
-cat gpurun_out/bench_base_r02.json | cut -c1-700; grep -i "capture\|graph" gpurun_out/bench_base_r02.err | head -5
-timeout -k 10 400 python bench.py --config hrnet_w32_384 --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/bench_w32_r02.json 2> gpurun_out/bench_w32_r02.err || { tail -5 gpurun_out/bench_w32_r02.err; exit 1; }
-cat gpurun_out/bench_w32_r02.json | cut -c1-700
+timeout -k 10 400 python bench.py --steps 40 --warmup 8 --no-cpu-baseline > gpurun_out/bench_tk.json 2> gpurun_out/bench_tk.err || { tail -5 gpurun_out/bench_tk.err; exit 1; }
+grep "roofline\|time_kernel" gpurun_out/bench_tk.err | cut -c1-200
+grep -o '"value": [0-9.]*\|"ms_per_step": [0-9.]*' gpurun_out/bench_tk.json | head -2

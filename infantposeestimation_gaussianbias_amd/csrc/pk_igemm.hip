@@ -1172,6 +1172,221 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
     }
 }
 
+// k_wgrad4w: the single-tap kernel for operands whose rows are GATHERED through the 7x7 window partition and / or SCALED per sample
+// (unfused attention: qkv weight gradient reads LN(x) in window order, proj reads dy in window order times the DropPath scale;
+// unfused MLP: fc2 reads dy times the scale).  Loading the int32 row map would put a dependent global load in front of every DMA
+// issue, so the map is RECOMPUTED: the caller passes the token grid (B, Hs, Ws) with the map (which must be nnops.window_rowmap of
+// that grid; M = B * ceil(Hs/7) * ceil(Ws/7) * 49 is checked), and every DMA lane carries (token in window, window x, window y,
+// sample) from step to step.  Row scales travel with the data: one 4-byte LDS-DMA per G piece fetches g_scale[sample] for the
+// piece's rows into a per-stage slot (lane-linear, i.e. one copy per 16-byte chunk of the row), the fragments are scaled in
+// registers after the transpose read (the bias gradient is the column sum of the SCALED rows, as in k_wgrad2).
+struct WinPos { int t, wx, wy, b; };
+__device__ __forceinline__ WinPos win_split(int m, int nw, int nh) {
+    WinPos r;
+    const int w = m / 49;
+    r.t = m - 49 * w;
+    const int q = w / nw;
+    r.wx = w - q * nw;
+    r.b = q / nh;
+    r.wy = q - r.b * nh;
+    return r;
+}
+__device__ __forceinline__ void win_advance(WinPos& r, int nw, int nh) {      // + 32 rows (< 49: at most one window further)
+    r.t += 32;
+    if (r.t >= 49) {
+        r.t -= 49;
+        if (++r.wx == nw) {
+            r.wx = 0;
+            if (++r.wy == nh) {
+                r.wy = 0;
+                ++r.b;
+            }
+        }
+    }
+}
+__device__ __forceinline__ int win_row(const WinPos& r, int H, int W) {       // pixel row of the token, -1 = zero-pad token
+    const int ty = (r.t * 37) >> 8, tx = r.t - 7 * ty;                         // t / 7, t % 7 for t < 49
+    const int y = r.wy * 7 + ty, x = r.wx * 7 + tx;
+    return (y < H && x < W) ? (r.b * H + y) * W + x : -1;
+}
+__device__ __forceinline__ float ring_f32(const float* a) {
+    float v;
+    asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void*)a) : "memory");
+    return v;
+}
+__device__ __forceinline__ s16x4 scale_bf16x4(const s16x4& v, const float* sc) {
+    const uint32_t lo = pack_bf16x2(__uint_as_float((uint32_t)(uint16_t)v[0] << 16) * sc[0], __uint_as_float((uint32_t)(uint16_t)v[1] << 16) * sc[1]);
+    const uint32_t hi = pack_bf16x2(__uint_as_float((uint32_t)(uint16_t)v[2] << 16) * sc[2], __uint_as_float((uint32_t)(uint16_t)v[3] << 16) * sc[3]);
+    return (s16x4){(short)(lo & 0xffff), (short)(lo >> 16), (short)(hi & 0xffff), (short)(hi >> 16)};
+}
+template <int TN, int TC>
+__global__ void __launch_bounds__(256, 2) k_wgrad4w(WgradArgs p) {
+    constexpr int ST = (TN + TC >= 256) ? 3 : 4;                  // ring <= 48 KB + <= 8 KB of row scales: two workgroups per CU
+    constexpr int PG = TN / 64, PX = TC / 64, PER = 2 * PG + PX;  // DMA instructions per wave and step: data pieces + one scale piece per G piece
+    constexpr int RG = 512 / TN, RX = 512 / TC;
+    constexpr int NI = TN / 32, CI = TC / 32;
+    constexpr int STAGE = 32 * (TN + TC), SCW = 4 * PG * 64;      // elements per stage; floats of row scales per stage
+    __shared__ __attribute__((aligned(1024))) uint16_t ring[ST * STAGE];
+    __shared__ __attribute__((aligned(1024))) float sS[ST * SCW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wc = wave & 1;
+    const int xcd = blockIdx.x & 7, k_in = blockIdx.x >> 3;
+    const int zslice = xcd + 8 * (k_in / p.ntiles3), tile3 = k_in % p.ntiles3;
+    if (zslice >= p.nslices3) return;
+    const int ntile = tile3 / p.ctiles, ctile = tile3 - ntile * p.ctiles;
+    const int n0 = ntile * TN, c0 = ctile * TC;
+    const int m_begin = zslice * p.m_per_slice;
+    const int m_end = min(p.M, m_begin + p.m_per_slice);
+    const int nsteps = (max(m_end - m_begin, 0) + 31) / 32;
+    const bool gwin = p.g_rowmap != nullptr, xwin = p.a_rowmap != nullptr, scaled = p.g_scale != nullptr;     // workgroup-uniform
+    const int nw = (p.Ws + 6) / 7, nh = (p.Hs + 6) / 7;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.g), 0, 0x7ffffff0, 0x00020000);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(scaled ? const_cast<float*>(p.g_scale) : (float*)const_cast<uint16_t*>(p.g), 0, 0x7ffffff0, 0x00020000);
+    int gm[PG], xm[PX], gsb[PG], gsr[PG];
+    unsigned gcb[PG], xcb[PX];                      // byte offset of the lane's chunk inside a source row
+    bool gcol[PG], xcol[PX];
+    WinPos gw[PG], xw[PX];
+#pragma unroll
+    for (int j = 0; j < PG; ++j) {
+        const int row = (wave + 4 * j) * RG + lane / (TN / 8);
+        const int col = n0 + (((lane % (TN / 8)) ^ w4_swz<TN>(row)) << 3);
+        gm[j] = m_begin + row;
+        gcol[j] = col < p.N;
+        gcb[j] = (unsigned)(col * 2);
+        gw[j] = gwin ? win_split(gm[j], nw, nh) : WinPos{0, 0, 0, 0};
+        gsb[j] = scaled ? gm[j] / p.g_rows_per_sample : 0;
+        gsr[j] = scaled ? gm[j] - gsb[j] * p.g_rows_per_sample : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int row = (wave + 4 * j) * RX + lane / (TC / 8);
+        const int col = c0 + (((lane % (TC / 8)) ^ w4_swz<TC>(row)) << 3);
+        xm[j] = m_begin + row;
+        xcol[j] = col < p.Cin;
+        xcb[j] = (unsigned)(col * 2);
+        xw[j] = xwin ? win_split(xm[j], nw, nh) : WinPos{0, 0, 0, 0};
+    }
+    int wr = 0;
+    auto issue_next = [&]() {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint16_t* sg = ring + wr * STAGE;
+        uint16_t* sx = sg + 32 * TN;
+        float* ss = sS + wr * SCW;
+        wr = (wr + 1 == ST) ? 0 : wr + 1;
+#pragma unroll
+        for (int j = 0; j < PG; ++j) {
+            const int src = gwin ? win_row(gw[j], p.Hs, p.Ws) : gm[j];
+            const bool live = gm[j] < m_end && src >= 0;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rg, W4_LDS(sg + (wave + 4 * j) * 512), 16,
+                                                     (live && gcol[j]) ? (unsigned)(src * p.N * 2) + gcb[j] : OOB_OFF, 0, 0, 0);
+            const int sample = gwin ? gw[j].b : gsb[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, W4_LDS(ss + (wave + 4 * j) * 64), 4, (live && scaled) ? (unsigned)(sample * 4) : OOB_OFF, 0, 0, 0);
+            gm[j] += 32;
+            if (gwin) win_advance(gw[j], nw, nh);
+            else if (scaled) {
+                gsr[j] += 32;
+                while (gsr[j] >= p.g_rows_per_sample) {
+                    gsr[j] -= p.g_rows_per_sample;
+                    ++gsb[j];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PX; ++j) {
+            const int src = xwin ? win_row(xw[j], p.Hs, p.Ws) : xm[j];
+            const bool live = xm[j] < m_end && src >= 0 && xcol[j];
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, W4_LDS(sx + (wave + 4 * j) * 512), 16, live ? (unsigned)(src * p.Cin * 2) + xcb[j] : OOB_OFF, 0, 0, 0);
+            xm[j] += 32;
+            if (xwin) win_advance(xw[j], nw, nh);
+        }
+#endif
+    };
+    f32x4 acc[NI][CI], accb[NI];
+#pragma unroll
+    for (int a = 0; a < NI; ++a) {
+        accb[a] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < CI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const bool do_bias = p.bias_part && ctile == 0 && wc == 0;
+    const bf16x8 ones = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+    // row scales of this lane's fragment rows 8 g .. 8 g + 7: piece = row / RG, one copy per chunk lane -> take the first
+    int sidx[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = 8 * (lane >> 4) + i;
+        sidx[i] = (r / RG) * 64 + (r % RG) * (TN / 8);
+    }
+#pragma unroll
+    for (int j = 0; j < ST - 1; ++j) issue_next();
+    int rd = 0;
+    for (int s = 0; s < nsteps; ++s) {
+        w4_wait_vm<(ST - 2) * PER>();
+        __builtin_amdgcn_s_barrier();
+        issue_next();
+        const uint16_t* sg = ring + rd * STAGE;
+        const uint16_t* sx = sg + 32 * TN;
+        const float* ss = sS + rd * SCW;
+        rd = (rd + 1 == ST) ? 0 : rd + 1;
+        s16x4 gl[NI], gh[NI], xl[CI], xh[CI];
+        float sc[8];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) w4_frag<TN>(sg, wn * (TN / 2) + a * 16, lane, gl[a], gh[a]);
+#pragma unroll
+        for (int b = 0; b < CI; ++b) w4_frag<TC>(sx, wc * (TC / 2) + b * 16, lane, xl[b], xh[b]);
+        if (scaled) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sc[i] = ring_f32(ss + sidx[i]);
+        }
+#pragma unroll
+        for (int a = 0; a < NI; a += 2) ring_fence4(gl[a], gh[a], gl[a + 1], gh[a + 1]);
+#pragma unroll
+        for (int b = 0; b < CI; b += 2) ring_fence4(xl[b], xh[b], xl[b + 1], xh[b + 1]);
+        if (scaled) {
+            asm volatile("" : "+v"(sc[0]), "+v"(sc[1]), "+v"(sc[2]), "+v"(sc[3]), "+v"(sc[4]), "+v"(sc[5]), "+v"(sc[6]), "+v"(sc[7]));
+#pragma unroll
+            for (int a = 0; a < NI; ++a) {
+                gl[a] = scale_bf16x4(gl[a], sc);
+                gh[a] = scale_bf16x4(gh[a], sc + 4);
+            }
+        }
+        bf16x8 gf[NI], xf[CI];
+#pragma unroll
+        for (int a = 0; a < NI; ++a) gf[a] = ring_join(gl[a], gh[a]);
+#pragma unroll
+        for (int b = 0; b < CI; ++b) xf[b] = ring_join(xl[b], xh[b]);
+#pragma unroll
+        for (int a = 0; a < NI; ++a)
+#pragma unroll
+            for (int b = 0; b < CI; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf[b], acc[a][b], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int a = 0; a < NI; ++a) accb[a] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], ones, accb[a], 0, 0, 0);
+        }
+    }
+    w4_wait_vm<0>();
+    float* dst = p.part + (size_t)zslice * p.N * p.Cin;
+#pragma unroll
+    for (int a = 0; a < NI; ++a) {
+        const int n = n0 + wn * (TN / 2) + a * 16 + (lane >> 4) * 4;
+#pragma unroll
+        for (int b = 0; b < CI; ++b) {
+            const int c = c0 + wc * (TC / 2) + b * 16 + (lane & 15);
+            if (c < p.Cin) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (n + r < p.N) dst[(size_t)(n + r) * p.Cin + c] = acc[a][b][r];
+            }
+        }
+        if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.N) p.bias_part[(size_t)zslice * p.N + n + r] = accb[a][r];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256, 2) k_wgrad4_3x3(WgradArgs p) {
     constexpr int W = 64, ST = 4, XR = 256;                                   // tile width, G stages, X ring rows
     __shared__ __attribute__((aligned(1024))) uint16_t sG[ST * 32 * W];       // 16 KB
@@ -1324,9 +1539,12 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4_3x3(WgradArgs p) {
     }
 }
 // which weight gradients the streaming kernels take: flags bit 0 = a_rowmap, 1 = g_rowmap, 2 = g_scale
-static inline int wgrad4_kind(int N, int Cin, int ksize, int stride, int Ws, int flags) {
-    static const int on = getenv("PK_WGRAD4") ? atoi(getenv("PK_WGRAD4")) : 7;      // bit 0: single tap, bit 1: nine-tap 3x3, bit 2: column-form 3x3
-    if (flags) return 0;
+static inline int wgrad4_kind(int N, int Cin, int ksize, int stride, int Hs, int Ws, int flags) {
+    static const int on = getenv("PK_WGRAD4") ? atoi(getenv("PK_WGRAD4")) : 15;     // bit 0: single tap, 1: nine-tap 3x3, 2: column-form 3x3, 3: window / scaled rows
+    if (flags) {       // gathered / scaled rows: linear form; a row map needs the token grid it is the window partition of
+        if (ksize != 1 || stride != 1 || ((flags & 3) && (Hs <= 0 || Ws <= 0))) return 0;
+        return (on & 8) ? 4 : 0;
+    }
     if (ksize == 1 && stride == 1) return (on & 1) ? 1 : 0;
     if (ksize == 3 && wgrad_wide(N, Cin, 9)) return 0;
     if (ksize == 3 && stride == 1 && Ws >= 1 && Ws <= 48) return (on & 2) ? 2 : 0;
@@ -1475,7 +1693,7 @@ static int wgrad_slices_old(int M, int N, int Cin, int T) {
 }
 static inline void wgrad4_tile(int N, int Cin, int kind, int& tn, int& tc) {
     tn = (kind == 2 || N <= 64) ? 64 : 128;
-    tc = (kind == 2 || (kind == 1 && Cin <= 64)) ? 64 : 128;         // column form: 9 * Cin >= 72 columns
+    tc = (kind == 2 || ((kind == 1 || kind == 4) && Cin <= 64)) ? 64 : 128;         // column form: 9 * Cin >= 72 columns
 }
 // padded-pixel count of the 3x3 form (the K range of k_wgrad4_3x3); M = B * Hs * Ws
 static inline int wgrad4_rows(int M, int Hs, int Ws, int kind) { return kind == 2 ? (M / (Hs * Ws)) * (Hs + 2) * (Ws + 2) : M; }
@@ -1493,7 +1711,7 @@ static int wgrad4_slices(int rows, int N, int Cin, int kind) {
     return s < 1 ? 1 : s;
 }
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int ksize, int stride, int Hs, int Ws, int flags) {
-    const int kind = wgrad4_kind(N, Cin, ksize, stride, Ws, flags);
+    const int kind = wgrad4_kind(N, Cin, ksize, stride, Hs, Ws, flags);
     if (kind) return wgrad4_slices(wgrad4_rows(M, Hs, Ws, kind), N, Cin, kind);
     return wgrad_slices_old(M, N, Cin, ksize * ksize);
 }
@@ -1513,7 +1731,7 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     a.x = (const uint16_t*)x; a.g = (const uint16_t*)grad_out; a.part = workspace; a.a_rowmap = a_rowmap; a.g_rowmap = g_rowmap;
     a.g_scale = g_scale; a.g_rows_per_sample = g_rows_per_sample > 0 ? g_rows_per_sample : 1;
     a.M = M; a.N = N; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo; a.stride = stride; a.pad = ksize / 2;
-    const int kind4 = wgrad4_kind(N, Cin, ksize, stride, Ws, (a_rowmap ? 1 : 0) | (g_rowmap ? 2 : 0) | (g_scale ? 4 : 0));
+    const int kind4 = wgrad4_kind(N, Cin, ksize, stride, Hs, Ws, (a_rowmap ? 1 : 0) | (g_rowmap ? 2 : 0) | (g_scale ? 4 : 0));
     const int S = pk_wgrad_slices(M, N, Cin, ksize, stride, Hs, Ws, (a_rowmap ? 1 : 0) | (g_rowmap ? 2 : 0) | (g_scale ? 4 : 0));
     PK_REQUIRE(n_bias >= 0 && n_bias <= N && (!dbias || n_bias > 0), "pk_wgrad_bf16: n_bias");
     a.bias_part = n_bias > 0 ? workspace + (size_t)S * N * a.T * Cin : nullptr;     // bias slabs follow the weight slabs
@@ -1524,7 +1742,13 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
     hipStream_t st = (hipStream_t)stream;
     PK_REQUIRE((int64_t)M * N < 0x3fffffffLL && (linear || (int64_t)B * Hs * Ws * Cin < 0x3fffffffLL), "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
     if (kind4) {
-        PK_SUPPORTED(kind4 == 1 || n_bias == 0, "pk_wgrad_bf16: the 3x3 streaming kernel has no bias-gradient path (convolutions here carry no bias)");
+        if (kind4 == 4 && (a_rowmap || g_rowmap)) {
+            const int nwin = ((Hs + 6) / 7) * ((Ws + 6) / 7);
+            PK_REQUIRE(B > 0 && M == B * nwin * 49, "pk_wgrad_bf16: M = %d is not the window-order row count of a (%d, %d, %d) token grid", M, B, Hs, Ws);
+            PK_REQUIRE(!g_scale || !g_rowmap || g_rows_per_sample == Hs * Ws, "pk_wgrad_bf16: g_rows_per_sample must be Hs * Ws with a window map");
+            PK_REQUIRE((int64_t)B * Hs * Ws * (N > Cin ? N : Cin) < 0x3fffffffLL, "pk_wgrad_bf16: tensor too large for 32-bit byte offsets");
+        }
+        PK_SUPPORTED(kind4 == 1 || kind4 == 4 || n_bias == 0, "pk_wgrad_bf16: the 3x3 streaming kernel has no bias-gradient path (convolutions here carry no bias)");
         PK_REQUIRE(linear || kind4 == 3 || (Ho == Hs && Wo == Ws), "pk_wgrad_bf16: stride-1 geometry");
         int t4n, t4c;
         wgrad4_tile(N, Cin, kind4, t4n, t4c);
@@ -1535,7 +1759,12 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
         a.nslices3 = S;
         a.m_per_slice = ((rows + S - 1) / S + 31) / 32 * 32;
         const dim3 grid(8 * ((S + 7) / 8) * a.ntiles3);
-        if (kind4 == 2) hipLaunchKernelGGL(k_wgrad4_3x3, grid, dim3(256), 0, st, a);
+        if (kind4 == 4) {
+            if (t4n == 64 && t4c == 64) hipLaunchKernelGGL((k_wgrad4w<64, 64>), grid, dim3(256), 0, st, a);
+            else if (t4n == 64) hipLaunchKernelGGL((k_wgrad4w<64, 128>), grid, dim3(256), 0, st, a);
+            else if (t4c == 64) hipLaunchKernelGGL((k_wgrad4w<128, 64>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((k_wgrad4w<128, 128>), grid, dim3(256), 0, st, a);
+        } else if (kind4 == 2) hipLaunchKernelGGL(k_wgrad4_3x3, grid, dim3(256), 0, st, a);
         else if (kind4 == 3 && t4n == 64) hipLaunchKernelGGL((k_wgrad4<64, 128, true>), grid, dim3(256), 0, st, a);
         else if (kind4 == 3) hipLaunchKernelGGL((k_wgrad4<128, 128, true>), grid, dim3(256), 0, st, a);
         else if (t4n == 64 && t4c == 64) hipLaunchKernelGGL((k_wgrad4<64, 64>), grid, dim3(256), 0, st, a);

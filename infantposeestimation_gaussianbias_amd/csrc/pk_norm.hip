@@ -32,8 +32,16 @@ __global__ void __launch_bounds__(16 * RED_LANES) k_sum_partials(const float* __
     const int col = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const int k = blockIdx.x * 16 + col;
     double s = 0.0;
-    if (k < K)
-        for (int b = rl; b < nb; b += RED_LANES) s += (double)part[(size_t)b * stride + k];
+    if (k < K) {
+        // four independent loads per round: the serial chain is memory latency x nb / 256, not x nb / 64
+        int b = rl;
+        for (; b + 3 * RED_LANES < nb; b += 4 * RED_LANES) {
+            const float v0 = part[(size_t)b * stride + k], v1 = part[(size_t)(b + RED_LANES) * stride + k];
+            const float v2 = part[(size_t)(b + 2 * RED_LANES) * stride + k], v3 = part[(size_t)(b + 3 * RED_LANES) * stride + k];
+            s += ((double)v0 + (double)v1) + ((double)v2 + (double)v3);
+        }
+        for (; b < nb; b += RED_LANES) s += (double)part[(size_t)b * stride + k];
+    }
     sh[rl][col] = s;
     __syncthreads();
     if (rl == 0 && k < K) {
@@ -68,11 +76,21 @@ __global__ void __launch_bounds__(16 * RED_LANES) k_bn_finalize(const float* __r
     const int c = blockIdx.x * 16 + col;
     if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
     double s = 0.0, q = 0.0;
-    if (c < C)
-        for (int t = rl; t < tiles; t += RED_LANES) {
+    if (c < C) {
+        int t = rl;
+        for (; t + 3 * RED_LANES < tiles; t += 4 * RED_LANES) {       // eight independent loads per round
+            const float* p0 = part + (size_t)t * 2 * C + c;
+            const size_t st = (size_t)RED_LANES * 2 * C;
+            const float s0 = p0[0], s1 = p0[st], s2 = p0[2 * st], s3 = p0[3 * st];
+            const float q0 = p0[C], q1 = p0[st + C], q2 = p0[2 * st + C], q3 = p0[3 * st + C];
+            s += ((double)s0 + (double)s1) + ((double)s2 + (double)s3);
+            q += ((double)q0 + (double)q1) + ((double)q2 + (double)q3);
+        }
+        for (; t < tiles; t += RED_LANES) {
             s += (double)part[(size_t)t * 2 * C + c];
             q += (double)part[(size_t)t * 2 * C + C + c];
         }
+    }
     sh[0][rl][col] = s;
     sh[1][rl][col] = q;
     __syncthreads();

@@ -350,14 +350,17 @@ def _conv_dgrad(g, wd, Cin, ksize, stride, in_hw):
 
 
 def _wgrad(x, g, N, Cin, ksize, stride, geom, a_map=None, g_map=None, g_scale=None, g_rps=0, M=None, oihw=True, out=None,
-           dbias=None, deferred=False):
+           dbias=None, deferred=False, win=None):
     """-> fp32 gradient (N, Cin, k, k) for conv (geom=(B,Hs,Ws,Ho,Wo)) or (N, Cin) for linear (geom=None); `out` = destination.
     `dbias` (fp32, <= N entries) additionally receives the bias gradient (column sums of the same scaled/gathered rows).
+    `win=(B, H, W)`: the row maps are nnops.window_rowmap(B, H, W) (lets the library take its streaming kernel, which recomputes the map).
     `deferred=True` (only when every output is a gradient sink, i.e. nothing downstream in backward reads the result): only the
     split-M slabs are written here, their reduction is postponed to finalize_deferred()."""
     T = ksize * ksize
     if geom is None:
         B = Hs = Ws = Ho = Wo = 0
+        if win is not None:        # (B, H, W) token grid whose window partition the row maps are: the streaming kernel recomputes them
+            B, Hs, Ws = win
     else:
         B, Hs, Ws, Ho, Wo = geom
         M = B * Ho * Wo
@@ -591,7 +594,7 @@ class _AttnHalf(torch.autograd.Function):
         dst, s_wp = _sink(pwproj)
         dbproj, s_bp = _sink(pbproj)
         dwproj = _wgrad(o, dy2, C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw, out=dst, dbias=dbproj,
-                        deferred=s_wp and s_bp)
+                        deferred=s_wp and s_bp, win=(B, H, W))
         # attention core
         dqkv = _e((Mw, 3 * C), BF16, dev)
         dtable, s_t = _sink(ptab)
@@ -609,7 +612,7 @@ class _AttnHalf(torch.autograd.Function):
         du = _linear(dqkv, wqkv_t, M, C, 3 * C, o_map=amap, M=Mw)
         dst, s_wq = _sink(pwqkv)
         dbqkv, s_bq = _sink(pbqkv)
-        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw, out=dst, dbias=dbqkv, deferred=s_wq and s_bq)
+        dwqkv = _wgrad(u, dqkv, 3 * C, C, 1, 1, None, a_map=amap, M=Mw, out=dst, dbias=dbqkv, deferred=s_wq and s_bq, win=(B, H, W))
         dx, dg1, db1 = _layernorm_bwd(du, x2, mean, rstd, g1, dy2, pg1, pb1, ctx.pad[0])
         return (dx.view(B, H, W, C), dg1, db1, None if s_t else dtable, None if s_wq else dwqkv, None if s_bq else dbqkv,
                 None if s_wp else dwproj, None if s_bp else dbproj, None, None, None, None)
@@ -881,7 +884,7 @@ class _AttnHalfFused(torch.autograd.Function):
         dst, s_wp = _sink(pwproj)
         dbproj, s_bp = _sink(pbproj)
         dwproj = _wgrad(o, dy.view(M, C), C, C, 1, 1, None, g_map=amap, g_scale=s1, g_rps=H * W, M=Mw, out=dst, dbias=dbproj,
-                        deferred=s_wp and s_bp)
+                        deferred=s_wp and s_bp, win=(B, H, W))
         return (dx, None if sg else dg, None if sb else db, None if s_t else dtable, None if s_wq else dwqkv, None if s_bq else dbqkv,
                 None if s_wp else dwproj, None if s_bp else dbproj, None, None)
 

@@ -273,6 +273,47 @@ def test_linear_rowmaps_gelu_residual(N):
     assert err(C(db), (gout * s.repeat_interleave(H * W)[:, None]).sum(0)) < 2e-3
 
 
+@pytest.mark.parametrize("B,H,W,Nn,Cc,mode", [(2, 9, 10, 32, 32, "gmap"), (3, 16, 12, 64, 64, "gmap"), (2, 16, 12, 128, 128, "gmap"),
+                                              (2, 9, 10, 96, 32, "amap"), (3, 16, 12, 192, 64, "amap"), (2, 8, 6, 768, 256, "amap"),
+                                              (4, 16, 12, 128, 512, "scale"), (5, 8, 6, 256, 1024, "scale"), (3, 7, 7, 40, 72, "gmap")])
+def test_wgrad_window_and_row_scale_streaming(N, B, H, W, Nn, Cc, mode):
+    """Weight gradients with window-gathered and / or per-sample scaled rows through the streaming kernel (win=(B,H,W): the library
+    recomputes the window map) against fp32, and bit-compatible in meaning with the map-loading kernel (same call without `win`).
+    dW[n][c] = sum_m G[m][n] X[m][c] over window-order rows m; bias gradient = column sums of the (gathered, scaled) G rows."""
+    amap, nwin = N.window_rowmap(B, H, W, DEV)
+    Mw, M = amap.numel(), B * H * W
+    am = amap.cpu().long()
+    valid = am >= 0
+    s = torch.tensor([0.0, 1.0 / 0.9, 1.0, 1.0 / 0.9, 0.0][:B])
+    dbias = torch.empty(Nn, device=DEV)
+    if mode == "gmap":          # proj: G = dy (pixel order) gathered + scaled, X = o (window order)
+        g_pix, xw = rnd(M, Nn, seed=1), rnd(Mw, Cc, seed=2)
+        gg = torch.zeros(Mw, Nn)
+        gg[valid] = g_pix[am[valid]] * s[am[valid] // (H * W)][:, None]
+        kw = dict(g_map=amap, g_scale=s.to(DEV), g_rps=H * W, M=Mw)
+        args = (xw.to(DEV, BF), g_pix.to(DEV, BF))
+        ref_w, ref_b = gg.T @ xw, gg.sum(0)
+    elif mode == "amap":        # qkv: X = LN(x) (pixel order) gathered, G = dqkv (window order)
+        x_pix, gw = rnd(M, Cc, seed=3), rnd(Mw, Nn, seed=4)
+        xg = torch.zeros(Mw, Cc)
+        xg[valid] = x_pix[am[valid]]
+        kw = dict(a_map=amap, M=Mw)
+        args = (x_pix.to(DEV, BF), gw.to(DEV, BF))
+        ref_w, ref_b = gw.T @ xg, gw.sum(0)
+    else:                       # fc2: G = dy scaled per sample, no maps
+        xh, g_pix = rnd(M, Cc, seed=5), rnd(M, Nn, seed=6)
+        gg = g_pix * s.repeat_interleave(H * W)[:, None]
+        kw = dict(g_scale=s.to(DEV), g_rps=H * W, M=M)
+        args = (xh.to(DEV, BF), g_pix.to(DEV, BF))
+        ref_w, ref_b = gg.T @ xh, gg.sum(0)
+    dw = N._wgrad(*args, Nn, Cc, 1, 1, None, dbias=dbias, win=(B, H, W), **kw)
+    assert err(C(dw), ref_w) < 1e-2 and err(C(dbias), ref_b) < 1e-2
+    if mode != "scale":         # the same launch without the token grid takes the map-loading kernel: same result up to summation order
+        db2 = torch.empty(Nn, device=DEV)
+        dw2 = N._wgrad(*args, Nn, Cc, 1, 1, None, dbias=db2, **kw)
+        assert err(C(dw), C(dw2)) < 2e-3 and err(C(dbias), C(db2)) < 2e-3
+
+
 # ------------------------------------------------------------------------------------------------ attention core
 @pytest.mark.parametrize("heads,Cc,nw", [(1, 32, 5), (2, 64, 3), (4, 128, 2), (8, 256, 300), (2, 32, 4), (4, 32, 3),
                                          (2, 80, 3), (1, 48, 2), (2, 128, 2), (3, 168, 70)])

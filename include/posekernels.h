@@ -266,9 +266,10 @@ int pk_nchw_f32_to_nhwc_bf16(const float* x, const float* softplus_out, void* y,
  * mode 0: dst[n][t][cp]=src[n][c][t] (forward), 1: dst[c][T-1-t][np]=src[n][c][t] (conv data-grad), 2: dst[c][np]=src[n][c] */
 /* Deferred parameter-gradient reductions: ONE launch for any number of slab sums  out[index(i)] = sum_{s<S} part[s*slab_stride + i], i < K.
  * desc_table rows (56 bytes): { const float* part; float* out; int64 slab_stride; int S, K, layout, N, T, Cin, out_stride, pad; };
- * layout 0: index(i) = i*out_stride; layout 1: i = (n*T + t)*Cin + c -> OIHW (n*Cin + c)*T + t; layout 2: i = a*Cin + b -> a*T + b*out_stride.  One 256-thread block per 64
- * outputs (block_desc = row, block_first = first block of that row).  Producers: pk_wgrad_bf16 (dw NULL), pk_layernorm_bwd
+ * layout 0: index(i) = i*out_stride; layout 1: i = (n*T + t)*Cin + c -> OIHW (n*Cin + c)*T + t; layout 2: i = a*Cin + b -> a*T + b*out_stride.  One 256-thread block per
+ * pk_reduce_many_cols() outputs (block_desc = row, block_first = first block of that row).  Producers: pk_wgrad_bf16 (dw NULL), pk_layernorm_bwd
  * (dgamma/dbeta NULL: partial is [blocks][2C]), pk_window_attn_bwd (dtable NULL: partial is [groups][169]).                   */
+int pk_reduce_many_cols(void);
 int pk_reduce_many(const void* desc_table, const int* block_desc, const int* block_first, int n_blocks, void* stream);
 int pk_pack_weights(void* flat_dst_bf16, const void* desc_table, const int32_t* block_desc, const int32_t* block_first,
                     int n_blocks, void* stream);

@@ -1602,7 +1602,8 @@ __global__ void __launch_bounds__(256) k_wgrad_reduce(const float* __restrict__ 
 // Fixed-order combine (deterministic).
 struct ReduceDesc { const float* part; float* out; int64_t slab_stride; int S, K, layout, N, T, Cin, out_stride, pad_; };
 // Block = 64 outputs (16 groups of 4 consecutive) x 16 slab-lanes: 16-byte loads, 256 contiguous bytes per slab row and block
-// (the first version read 64-byte pieces and ran at a quarter of the HBM rate: 1.17 ms per step for ~1.5 GB of slabs).
+// (the first version read 64-byte pieces and ran at a quarter of the HBM rate: 1.17 ms per step for ~1.5 GB of slabs.  Measured and
+// dropped in round 2: 1 KiB contiguous per slab row x 4 slab-lanes with four rows in flight per lane -- 1 310 us instead of 686 us.)
 __global__ void __launch_bounds__(256) k_reduce_many(const ReduceDesc* __restrict__ desc, const int* __restrict__ blk_desc,
                                                      const int* __restrict__ blk_first) {
     __shared__ float4 sh[16][17];
@@ -1649,6 +1650,7 @@ __global__ void __launch_bounds__(256) k_reduce_many(const ReduceDesc* __restric
         }
     }
 }
+extern "C" int pk_reduce_many_cols(void) { return 64; }     /* outputs per block: n_blocks = sum over rows of ceil(K / this) */
 extern "C" int pk_reduce_many(const void* desc_table, const int* block_desc, const int* block_first, int n_blocks, void* stream) {
     PK_REQUIRE(desc_table && block_desc && block_first && n_blocks > 0, "pk_reduce_many: bad argument");
     hipLaunchKernelGGL(k_reduce_many, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream, (const ReduceDesc*)desc_table, block_desc, block_first);

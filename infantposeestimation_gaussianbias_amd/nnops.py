@@ -126,8 +126,9 @@ def _defer(part_ptr, out, slab_stride, S, K, layout=0, N=0, T=1, Cin=1, out_stri
 def _reduce_table(key, dev):
     desc = np.array(list(key), dtype=_REDUCE_DTYPE)
     blk_desc, blk_first, nb = [], [], 0
+    cols = _lib.lib.pk_reduce_many_cols()
     for i, r in enumerate(key):
-        k = -(-r[4] // 64)
+        k = -(-r[4] // cols)
         blk_desc += [i] * k
         blk_first += [nb] * k
         nb += k

@@ -641,7 +641,7 @@ def test_eval_forward_between_graph_replays_sees_current_weights():
 
 def test_deferred_reductions_match_inline_reductions(monkeypatch):
     """Parameter gradients with the slab reductions postponed to ONE pk_reduce_many launch equal the ones produced by the
-    per-layer reduce kernels (same slabs; only LayerNorm / rel-pos-bias sums use a different fixed summation tree)."""
+    per-layer reduce kernels (same slabs; the two kernels use different fixed fp32 summation trees: equal to rounding)."""
     from infantposeestimation_gaussianbias_amd import engine
     from infantposeestimation_gaussianbias_amd.configs import get_config
     from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
@@ -665,10 +665,7 @@ def test_deferred_reductions_match_inline_reductions(monkeypatch):
         # sink-mode gradients (stored by the backward kernels) == autograd-mode gradients of the first pass
         assert float((auto - grads[defer]).norm() / auto.norm()) < 1e-5
     a, b = grads["0"], grads["1"]
-    assert float((a - b).abs().max() / a.abs().max()) < 1e-6
-    names = [n for n, p, o in zip(tr.opt.names, tr.opt.params, tr.opt.offsets)
-             if not torch.equal(a[o:o + p.numel()], b[o:o + p.numel()])]
-    assert all(("norm" in n) or ("relative_position_bias_table" in n) for n in names), names[:5]   # weight/bias gradients: bit-identical
+    assert float((a - b).abs().max() / a.abs().max()) < 1e-6      # same slabs, two fixed fp32 summation trees
 
 
 def test_graph_with_branch_streams_matches_eager_steps():

@@ -968,7 +968,12 @@ def fuse_sum(xs, relu=True):
 
 
 def exchange(xs, fuse, training, n_out=None):
-    """Exchange unit (hrformer.py:462-491 == hrnet.py:198-227): out_i = relu(sum_j route_{j->i}(x_j))."""
+    """Exchange unit (hrformer.py:462-491 == hrnet.py:198-227): out_i = relu(sum_j route_{j->i}(x_j)).
+
+    One parallel task per OUTPUT.  (Measured and dropped: one task per ROUTE j -> i, i.e. 12 shorter chains plus a second region for
+    the sums -- 19.15 -> 19.5 ms per step: hipGraph runs parallel branches on four hardware queues, more branches only add fork /
+    join edges.  The unit stays a chain of launch-latency-bound kernels on small tensors: ~0.3 ms backward per unit with ~0.3
+    kernels in flight, profiles/r02_trace_summary.txt.)"""
     from . import dispatch
     n = len(xs)
 

@@ -126,10 +126,12 @@ def roofline_table(model, B):
         # Weight gradients as the step launches them: slabs only (dw = NULL), the split-M partial sums of ALL layers are reduced by
         # the step's one k_reduce_many launch.
         def wgrad_slabs(xx, gg, Mr, N_, Cin_, ks, geom, a_map=None):
+            # geom: (B, H, W) of the conv input, or -- linear form with a window row map -- of the token grid the map partitions
             Bq, Hq, Wq = geom if geom else (0, 0, 0)
+            Ho, Wo = (0, 0) if a_map is not None else (Hq, Wq)
             S = _lib.lib.pk_wgrad_slices(Mr, N_, Cin_, ks, 1, Hq, Wq, 1 if a_map is not None else 0)
             ws = torch.empty(S * N_ * (ks * ks * Cin_ + 1), device=dev)
-            return lambda: call("pk_wgrad_bf16", xx, gg, ws, None, None, 0, a_map, None, None, 0, Mr, N_, Cin_, ks, 1, Bq, Hq, Wq, Hq, Wq, 0,
+            return lambda: call("pk_wgrad_bf16", xx, gg, ws, None, None, 0, a_map, None, None, 0, Mr, N_, Cin_, ks, 1, Bq, Hq, Wq, Ho, Wo, 0,
                                 stream_ptr())
         # 2. the head conv's weight gradient: k_wgrad3 (256 x 256 tile, 4-stage LDS-DMA ring), 3 launches per step
         sec = time_kernel(wgrad_slabs(x, g, M, C, C, 3, (B, H, W)))
@@ -141,14 +143,14 @@ def roofline_table(model, B):
         sec = time_kernel(wgrad_slabs(u, dq, Mw, 96, 32, 1, None))
         out.append(_entry("k_wgrad4<128,64>", "qkv weight gradient, branch 0: 219520 tokens x 96 x 32 (slabs)", "hbm", sec,
                           flops=2.0 * Mw * 96 * 32, bytes_=2.0 * Mw * (96 + 32), launches=14))
-        # 3b. k_wgrad2<64,64,32> (81 launches: the weight gradients that still take a window row map or a DropPath row scale):
-        # dominant shape = qkv weight gradient of the branch-1 blocks, x gathered through the window map
+        # 3b. k_wgrad4w<128,64> (windowed / row-scaled streaming kernel, 104 launches over its four tile variants): qkv weight gradient of
+        # the branch-1 blocks, x gathered through the 7x7 window partition (recomputed per DMA lane)
         amap1, nwin1 = nnops.window_rowmap(B, 32, 24, dev)
         Mw1 = amap1.numel()
         u1, dq1 = torch.randn(B * 32 * 24, 64, device=dev).to(BF), torch.randn(Mw1, 192, device=dev).to(BF)
-        sec = time_kernel(wgrad_slabs(u1, dq1, Mw1, 192, 64, 1, None, a_map=amap1))
-        out.append(_entry("k_wgrad2<64,64,32>", f"qkv weight gradient, branch 1: {Mw1} window tokens x 192 x 64, gathered rows (slabs)", "hbm",
-                          sec, flops=2.0 * Mw1 * 192 * 64, bytes_=2.0 * (Mw1 * 192 + B * 32 * 24 * 64), launches=81))
+        sec = time_kernel(wgrad_slabs(u1, dq1, Mw1, 192, 64, 1, (B, 32, 24), a_map=amap1))
+        out.append(_entry("k_wgrad4w<128,64>", f"qkv weight gradient, branch 1: {Mw1} window tokens x 192 x 64, gathered rows (slabs)", "hbm",
+                          sec, flops=2.0 * Mw1 * 192 * 64, bytes_=2.0 * (Mw1 * 192 + B * 32 * 24 * 64), launches=14))
         # 4. k_igemm2<128,64,4,1,64>: dominant shape = 3x3 conv 64->64 @64x48 (layer1 / transition convs), forward with BN statistics
         x64 = torch.randn(B, H, W, 64, device=dev).to(BF)
         w64 = torch.randn(64, 9, 64, device=dev).to(BF)

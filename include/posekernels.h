@@ -145,9 +145,12 @@ int pk_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
  * sums / sums of squares of the fp32 results for train-mode BatchNorm.  dilated_input=1 evaluates the stride-2
  * data-gradient (input rows/cols are the zero-stuffed output gradient; pass flipped weights, mode 1 of pk_pack_weights).
  * act: 0 none, 2 softplus (nn.Softplus of fusion_head.py:250).                                                      */
+/* addend (optional, bf16, shape of the output, out_mode 0, no statistics): out = conv(x) + addend.  Used by the data-gradient launch
+ * of the first conv of a residual block (hrnet.py:44-52,92-102): the skip connection's gradient is added in the epilogue instead
+ * of by a separate elementwise pass over both gradients.                                                                       */
 int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, float* stats_partial, const float* bias,
                    int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int dilated_input, int Ho, int Wo,
-                   int act, int out_mode, void* stream);
+                   int act, int out_mode, const void* addend, void* stream);
 int pk_conv_stats_tiles(int M);
 
 /* A1/A3 linear layers: nn.Linear qkv/proj (models/hrformer.py:167-169,180,197) and Mlp fc1/fc2 (:53-55,58-64).

@@ -593,7 +593,7 @@ static int check_common(const char* who, const void* x, const void* w, const voi
 
 extern "C" int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, float* stats_partial, const float* bias,
                               int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int dilated_input, int Ho,
-                              int Wo, int act, int out_mode, void* stream) {
+                              int Wo, int act, int out_mode, const void* addend, void* stream) {
     const int M = B * Ho * Wo;
     int rc = check_common("pk_conv2d_nhwc", x, w_packed, out, M, Cout, Cin, Cout, out_mode);
     if (rc) return rc;
@@ -616,6 +616,8 @@ extern "C" int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, fl
     a.M = M; a.N = Cout; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo;
     a.stride = stride; a.pad = ksize / 2; a.dilated = dilated_input; a.ldo = Cout; a.rows_per_sample = Ho * Wo;
     a.act = act; a.out_mode = out_mode;
+    PK_REQUIRE(!addend || (out_mode == 0 && !stats_partial), "pk_conv2d_nhwc: an addend needs the bf16 row-major output and no statistics");
+    a.res = (const uint16_t*)addend;          // out = conv(x) + addend (same shape, bf16): the skip connection's gradient in a data-gradient launch
     return igemm_launch(a, (hipStream_t)stream, "pk_conv2d_nhwc");
 }
 

@@ -42,13 +42,13 @@ class Residual(nn.Module):
             with nnops.scope(self):
                 return nnops.to_public(self.forward(nnops.from_public(x)))
         tr = self.training
-        y = nnops.conv_bn_act(x, self.conv1, self.bn1, True, None, tr)
         if not self.bottleneck:
-            return nnops.conv_bn_act(y, self.conv2, self.bn2, True, x, tr)
+            return nnops.residual_block(x, (self.conv1, self.bn1), [], (self.conv2, self.bn2), tr)
+        if not hasattr(self, "downsample"):
+            return nnops.residual_block(x, (self.conv1, self.bn1), [(self.conv2, self.bn2)], (self.conv3, self.bn3), tr)
+        y = nnops.conv_bn_act(x, self.conv1, self.bn1, True, None, tr)
         y = nnops.conv_bn_act(y, self.conv2, self.bn2, True, None, tr)
-        res = x
-        if hasattr(self, "downsample"):
-            res = nnops.conv_bn_act(x, self.downsample[0], self.downsample[1], False, None, tr)
+        res = nnops.conv_bn_act(x, self.downsample[0], self.downsample[1], False, None, tr)
         return nnops.conv_bn_act(y, self.conv3, self.bn3, True, res, tr)
 
 

@@ -337,16 +337,17 @@ def _conv_raw(x, wf, Cout, ksize, stride, stats):
     if stats:
         tiles = _lib.lib.pk_conv_stats_tiles(B * Ho * Wo)
         part = _e((tiles, 2, Cout), F32, x.device)
-    call("pk_conv2d_nhwc", x, wf, raw, part, None, B, Hs, Ws, Cin, Cout, ksize, stride, 0, Ho, Wo, 0, 0, stream_ptr())
+    call("pk_conv2d_nhwc", x, wf, raw, part, None, B, Hs, Ws, Cin, Cout, ksize, stride, 0, Ho, Wo, 0, 0, None, stream_ptr())
     return raw, part
 
 
-def _conv_dgrad(g, wd, Cin, ksize, stride, in_hw):
-    """g (B,Ho,Wo,Cout) -> dx (B,Hs,Ws,Cin) with the flipped / transposed weight copy `wd` [Cin][T][Cout_pad]."""
+def _conv_dgrad(g, wd, Cin, ksize, stride, in_hw, addend=None):
+    """g (B,Ho,Wo,Cout) -> dx (B,Hs,Ws,Cin) with the flipped / transposed weight copy `wd` [Cin][T][Cout_pad]; `addend` (shape of dx)
+    is added in the epilogue (the skip connection's gradient of a residual block)."""
     B, Ho, Wo, Cout = g.shape
     Hs, Ws = in_hw
     dx = _e((B, Hs, Ws, Cin), BF16, g.device)
-    call("pk_conv2d_nhwc", g, wd, dx, None, None, B, Ho, Wo, Cout, Cin, ksize, 1, 1 if stride == 2 else 0, Hs, Ws, 0, 0, stream_ptr())
+    call("pk_conv2d_nhwc", g, wd, dx, None, None, B, Ho, Wo, Cout, Cin, ksize, 1, 1 if stride == 2 else 0, Hs, Ws, 0, 0, addend, stream_ptr())
     return dx
 
 
@@ -397,10 +398,23 @@ def _colsum(g, rows, N, rowmap=None, row_scale=None, rps=0, out=None):
 
 
 # ================================================================================================ conv + BN (+res) (+ReLU)
+class SkipGrad:
+    """Hand-over of a residual block's skip gradient (hrnet.py:44-52,92-102: out = relu(bn(conv_last(..conv_first(x)..)) + x)).  The block's
+    LAST conv takes the skip input detached and stores the skip's gradient here in its backward; the block's FIRST conv -- whose
+    backward runs later, it is upstream on the same chain -- adds it in the epilogue of its data-gradient launch.  Autograd then sees
+    ONE consumer of x and does not launch an elementwise add over two full-size gradients (5 per step in HRFormer-small's layer1, one per
+    BasicBlock in HRNet)."""
+    __slots__ = ("g",)
+
+    def __init__(self):
+        self.g = None
+
+
 class _ConvBnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, relu, training):
+    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, relu, training, skip_out=None, skip_in=None):
         ctx.params = (weight, gamma, beta)
+        ctx.skip_out, ctx.skip_in = skip_out, skip_in      # skip_out: store d(residual) there; skip_in: add what was stored to dx
         wc = _wc()
         wf, wd = wc.fwd[id(weight)], wc.dgrad[id(weight)]
         Cout, Cin_real, ksize = weight.shape[0], weight.shape[1], weight.shape[2]
@@ -441,7 +455,14 @@ class _ConvBnAct(torch.autograd.Function):
         # (eval mode, bit 1: the running statistics are constants, the input gradient is gamma * rstd * g without the batch-mean terms)
         call("pk_bn_bwd", dy, y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, dres, M, Cout, (1 if relu else 0) | (0 if training else 2),
              stream_ptr())
-        dx = _conv_dgrad(draw, wd, Cin, ksize, stride, (Hs, Ws)) if ctx.needs_input_grad[0] else None
+        addend = None
+        if ctx.skip_in is not None:
+            addend, ctx.skip_in.g = ctx.skip_in.g, None
+            if addend is None:
+                raise _lib.PoseKernelError("residual block backward out of order: the skip gradient has not been produced yet")
+        if ctx.skip_out is not None:
+            ctx.skip_out.g, dres = dres, None                # handed to the block's first conv instead of to autograd
+        dx = _conv_dgrad(draw, wd, Cin, ksize, stride, (Hs, Ws), addend) if (ctx.needs_input_grad[0] or addend is not None) else None
         if Cin != Cin_real:                # stem: 3 real input channels inside 8-channel pixels
             dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo))[:, :Cin_real].contiguous()
             dst = grad_sink_of(w_p)
@@ -452,11 +473,22 @@ class _ConvBnAct(torch.autograd.Function):
             dst, sw = _sink(w_p)
             dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo), out=dst, deferred=sw)
             dw = None if sw else dw
-        return dx, dw, None if sg else dgamma, None if sb else dbeta, dres, None, None, None, None
+        return dx, dw, None if sg else dgamma, None if sb else dbeta, dres, None, None, None, None, None, None
 
 
-def conv_bn_act(x, conv, bn, relu=False, residual=None, training=False):
-    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], relu, training)
+def conv_bn_act(x, conv, bn, relu=False, residual=None, training=False, skip_out=None, skip_in=None):
+    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], relu, training, skip_out, skip_in)
+
+
+def residual_block(x, first, middle, last, training):
+    """relu(bn(conv_last(...relu(bn(conv_first(x)))...)) + x) with an IDENTITY skip; first / last = (conv, bn), middle = list of (conv, bn).
+    In training the skip gradient bypasses autograd (SkipGrad); otherwise this is the plain chain."""
+    fuse = training and torch.is_grad_enabled() and x.requires_grad and first[0].stride[0] == 1 and os.environ.get("POSE_SKIP_GRAD", "1") != "0"
+    hold = SkipGrad() if fuse else None
+    y = conv_bn_act(x, first[0], first[1], True, None, training, skip_in=hold)
+    for conv, bn in middle:
+        y = conv_bn_act(y, conv, bn, True, None, training)
+    return conv_bn_act(y, last[0], last[1], True, x.detach() if fuse else x, training, skip_out=hold)
 
 
 # ================================================================================================ head output conv
@@ -470,7 +502,7 @@ class _HeadOut(torch.autograd.Function):
         B, H, W, Cin = x.shape
         N = weight.shape[0]
         out = _e((B, N, H, W), F32, x.device)
-        call("pk_conv2d_nhwc", x, wf, out, None, bias, B, H, W, Cin, N, 1, 1, 0, H, W, 2 if softplus else 0, 2, stream_ptr())
+        call("pk_conv2d_nhwc", x, wf, out, None, bias, B, H, W, Cin, N, 1, 1, 0, H, W, 2 if softplus else 0, 2, None, stream_ptr())
         ctx.save_for_backward(x, out if softplus else x.new_empty(0), wd)
         ctx.meta = (softplus, N)
         return out
@@ -484,7 +516,7 @@ class _HeadOut(torch.autograd.Function):
         g = _e((B, H, W, Np), BF16, x.device)
         call("pk_nchw_f32_to_nhwc_bf16", dout.contiguous(), y if softplus else None, g, B, N, H, W, Np, stream_ptr())
         dx = _e((B, H, W, Cin), BF16, x.device)
-        call("pk_conv2d_nhwc", g, wd, dx, None, None, B, H, W, Np, Cin, 1, 1, 0, H, W, 0, 0, stream_ptr())
+        call("pk_conv2d_nhwc", g, wd, dx, None, None, B, H, W, Np, Cin, 1, 1, 0, H, W, 0, 0, None, stream_ptr())
         w_p, b_p = ctx.params
         db = _e((N,), F32, x.device)
         dw = _wgrad(x, g, Np, Cin, 1, 1, (B, H, W, H, W), dbias=db)[:N]

@@ -92,7 +92,7 @@ def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
         out = torch.empty(B, Ho, Wo, Cout, device=DEV)
         tiles = lib.pk_conv_stats_tiles(B * Ho * Wo)
         part = torch.empty(tiles, 2, Cout, device=DEV)
-        call("pk_conv2d_nhwc", xd, wf, out, part, None, B, H, W, Cin, Cout, k, s, 0, Ho, Wo, 0, 1, stream_ptr())
+        call("pk_conv2d_nhwc", xd, wf, out, part, None, B, H, W, Cin, Cout, k, s, 0, Ho, Wo, 0, 1, None, stream_ptr())
         assert err(nchw(out), ref.detach()) < 2e-3                                   # fp32 output: accumulation order only
         st = C(part).sum(0)
         assert err(st[0], ref.detach().sum((0, 2, 3))) < 2e-3

@@ -214,12 +214,14 @@ class WeightCache:
                 T = w.shape[2] * w.shape[3] if w.dim() == 4 else 1
                 self.entries.append((w, N, C, T))
         self.fwd, self.dgrad = {}, {}
+        self.bn_eval = {}          # id(BatchNorm module) -> (key, scale, shift, mean, rstd): eval-mode constants, see _ConvBnAct
         self._sig = None
         self._dirty = True
         self.flat = None
 
     def mark_dirty(self):
         self._dirty = True
+        self.bn_eval.clear()
 
     def _signature(self):
         return tuple((w.data_ptr(), w._version) for w, _, _, _ in self.entries)
@@ -266,6 +268,7 @@ class WeightCache:
         if self._dirty or sig != self._sig:
             call("pk_pack_weights", self.flat, self._desc, self._blk_desc, self._blk_first, self._nb, stream_ptr())
             self._sig, self._dirty = sig, False
+            self.bn_eval.clear()               # eval-mode BatchNorm constants derive from parameters that just changed
 
 
 def weight_cache(model) -> WeightCache:
@@ -426,13 +429,23 @@ class _ConvBnAct(torch.autograd.Function):
         scale, shift = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
         mean, rstd = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
         if training:
+            wc.bn_eval.pop(id(bn), None)        # the kernel below rewrites the running statistics in place (no version bump)
             call("pk_bn_finalize", part, part.shape[0], Cout, M, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
                  0.1, 1e-5, scale, shift, mean, rstd, stream_ptr())
         else:
-            torch.rsqrt(bn.running_var + 1e-5, out=rstd)
-            torch.mul(gamma, rstd, out=scale)
-            torch.addcmul(beta, bn.running_mean, scale, value=-1.0, out=shift)
-            mean.copy_(bn.running_mean)
+            # eval: scale / shift are constants of the parameters -- computed once (4 small ATen launches) and kept until the weights or
+            # the statistics change (was: 4 launches per BatchNorm layer and forward, 320 per HRFormer-base inference step)
+            key = (gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version, bn.running_mean.data_ptr(), bn.running_mean._version,
+                   bn.running_var.data_ptr(), bn.running_var._version)
+            ent = wc.bn_eval.get(id(bn))
+            if ent is None or ent[0] != key:
+                torch.rsqrt(bn.running_var + 1e-5, out=rstd)
+                torch.mul(gamma, rstd, out=scale)
+                torch.addcmul(beta, bn.running_mean, scale, value=-1.0, out=shift)
+                mean.copy_(bn.running_mean)
+                wc.bn_eval[id(bn)] = (key, scale, shift, mean, rstd)
+            else:
+                _, scale, shift, mean, rstd = ent
         y = _e(raw.shape, BF16, dev)
         res = None if residual is None else residual.contiguous()
         call("pk_bn_act", raw, scale, shift, res, y, M, Cout, 1 if relu else 0, stream_ptr())

@@ -833,6 +833,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TN == 
 //     transpose reads `ds_read_b64_tr_b16` of a 32-lane half (rows r..r+3 and r+8..r+11, 32 columns) then touch 32 distinct
 //     8-byte bank pairs (without it all rows alias: 8-way conflicts).
 // One workgroup per CU (128 KB of LDS), 1-D grid of 9 taps x S slices ~ one round of workgroups with equal work.
+// (Measured and dropped: software-pipelining the fragment reads of step s + 1 under the MFMAs of step s inside every wave -- behind the
+// per-step barrier the eight waves read together and multiply together -- needs a second register set for G (and X): 128 accumulators
+// + 64..80 fragment registers + addresses do not fit 256 VGPRs at two waves per SIMD; 110 spills, and scratch traffic shares vmcnt
+// with the DMA ring.)
 // LDS reads of tiles that are filled by LDS-DMA go through inline assembly.  The compiler cannot tell which LDS bytes an outstanding
 // `buffer_load ... lds` will write, so before any ds_read it can see it inserts `s_waitcnt vmcnt(0)`: the tile requested a moment ago
 // is awaited BEFORE the current one is multiplied: a four-deep ring is drained on every step (first version of k_wgrad3: 25 % of

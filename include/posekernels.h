@@ -166,6 +166,11 @@ int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, c
  * out_layout 0: [N][k*k][Cin]; 1: OIHW (the reference's nn.Conv2d.weight layout).  Ho == 0 selects the linear form.
  * dbias (optional, n_bias <= N entries): the bias gradient = column sums of the same (gathered, scaled) grad_out rows,
  * accumulated from the tile already staged in LDS.                                                                       */
+/* Row maps (linear form): a_rowmap / g_rowmap give the source row of x / grad_out for GEMM row m (-1 = zero row); g_scale multiplies
+ * grad_out row r by g_scale[r / g_rows_per_sample] (DropPath).  When the maps are the 7x7 WINDOW PARTITION of a (B, Hs, Ws) token
+ * grid (nnops.window_rowmap: m = ((b*nh + wy)*nw + wx)*49 + ty*7 + tx -> pixel (wy*7+ty, wx*7+tx), pad tokens -1), pass B, Hs, Ws
+ * with Ho = Wo = 0: the streaming kernel then RECOMPUTES the map per DMA lane instead of loading it (M must equal B*nh*nw*49, and
+ * g_rows_per_sample must be Hs*Ws).  With B = Hs = Ws = 0 the map is loaded (any map, slower kernel).                          */
 /* dw == NULL: write the slabs only (weight slabs [S][N*k*k*Cin], then bias slabs [S][N] when n_bias > 0) and let the caller
  * reduce them later with pk_reduce_many.                                                                                  */
 /* pk_wgrad_slices: the slab count S of the launch pk_wgrad_bf16 will make for the same arguments (Hs = Ws = 0 for the linear

@@ -1017,7 +1017,9 @@ def exchange(xs, fuse, training, n_out=None):
 
     One parallel task per OUTPUT.  (Measured and dropped: one task per ROUTE j -> i, i.e. 12 shorter chains plus a second region for
     the sums -- 19.15 -> 19.5 ms per step: hipGraph runs parallel branches on four hardware queues, more branches only add fork /
-    join edges.  The unit stays a chain of launch-latency-bound kernels on small tensors: ~0.3 ms backward per unit with ~0.3
+    join edges; and packing the routes into four tasks of equal layer count (4 + 4 + 4 + 4 instead of 3 + 3 + 4 + 6) with the sums
+    afterwards -- 18.9 -> 19.2 .. 19.5 ms: every x_j then also gets a gradient from outside the region, i.e. four extra elementwise
+    adds per unit on the main stream.  The unit stays a chain of launch-latency-bound kernels on small tensors: ~0.3 ms backward per unit with ~0.3
     kernels in flight, profiles/r02_trace_summary.txt.)"""
     from . import dispatch
     n = len(xs)

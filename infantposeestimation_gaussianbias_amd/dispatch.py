@@ -64,8 +64,8 @@ def ops():
 
 
 # the network ops themselves (they refuse to run outside a scope: nnops._wc() raises without an active weight cache)
-from .nnops import (backward_milestone, conv_bn_act, drop_scales, exchange, head_out, mlp_rows, residual_block, to_features,  # noqa: E402,F401
-                    window_attention_tokens, window_block)
+from .nnops import (backward_milestone, conv_bn_act, drop_scales, exchange, exchange_output, head_out, mlp_rows, residual_block,  # noqa: E402,F401
+                    to_features, window_attention_tokens, window_block)
 
 
 def to_public(x):

@@ -7,6 +7,8 @@ exchange unit after every module; only output 0 of the last module is returned (
 """
 from typing import Sequence
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -71,6 +73,9 @@ class HRFormerBlock(nn.Module):
             return nnops.to_public(nnops.window_block(t, self, self.heads, s1, s2))
 
 
+_CHAIN = os.environ.get("POSE_CHAIN_MODULES", "1") != "0"
+
+
 class HRFormerModule(nn.Module):
     def __init__(self, channels, heads, blocks_per_branch, mlp_ratios, drop_path):
         super().__init__()
@@ -83,12 +88,20 @@ class HRFormerModule(nn.Module):
     def n_draws(self):
         return 2 * sum(len(b) for b in self.branches)
 
-    def forward(self, xs, scales=None):
-        """scales: (n_draws, B) DropPath multipliers for this module (two per block, branch-major), or None."""
+    def forward(self, xs, scales=None, pre=None, defer=False):
+        """scales: (n_draws, B) DropPath multipliers for this module (two per block, branch-major), or None.
+
+        Chaining (same stage, same branch count): with `defer=True` the module returns its branch outputs WITHOUT the exchange unit;
+        the next module gets them as `xs` together with `pre` = this module's fuse layers and computes exchange output i INSIDE its
+        branch task i.  One fork/join per module instead of two, and branch i (the long high-resolution one in particular) starts
+        as soon as its own input is summed instead of after the slowest exchange output (output 3: six conv + BN layers)."""
+        n_prev = len(xs)
+
         def make(b, blocks, d0):
             def run(ins):
-                t, d = ins[0], d0
-                sc = ins[1] if len(ins) > 1 else None
+                t, d = (nnops.exchange_output(b, ins[:n_prev], pre, self.training) if pre is not None else ins[0]), d0
+                k = n_prev if pre is not None else 1
+                sc = ins[k] if len(ins) > k else None
                 for blk in blocks:
                     s1, s2 = (sc[d], sc[d + 1]) if sc is not None else (None, None)
                     d += 2
@@ -100,8 +113,9 @@ class HRFormerModule(nn.Module):
         for b, blocks in enumerate(self.branches):
             fns.append(make(b, blocks, d))
             d += 2 * len(blocks)
-        ys = nnops.parallel(fns, [[xs[b]] + ([scales] if scales is not None else []) for b in range(len(fns))])
-        if len(ys) == 1:
+        extra = [scales] if scales is not None else []
+        ys = nnops.parallel(fns, [(list(xs) if pre is not None else [xs[b]]) + extra for b in range(len(fns))])
+        if len(ys) == 1 or defer:
             return ys
         return nnops.exchange(ys, self.fuse_layers, self.training)
 
@@ -163,9 +177,12 @@ class HRFormer(nn.Module):
         d = 0
         for s in (2, 3, 4):
             ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
-            for m in getattr(self, f"stage{s}"):
+            mods_s, pre = list(getattr(self, f"stage{s}")), None
+            for k, m in enumerate(mods_s):
                 n = m.n_draws()
-                ys = m(ys, None if scales is None else scales[d:d + n])
+                chain = _CHAIN and k + 1 < len(mods_s)          # the exchange unit of this module runs inside the next module's tasks
+                ys = m(ys, None if scales is None else scales[d:d + n], pre=pre, defer=chain)
+                pre = m.fuse_layers if chain else None
                 d += n
             # N > 1: once backward has passed this boundary the later stages' gradients are exchanged while the earlier stages still
             # run backward (only output 0 of the last stage is consumed, hrformer.py:776 / hrnet.py:441)

@@ -3,6 +3,8 @@
 Stem -> 4 bottlenecks -> stage2 (1 module) -> stage3 (4 modules) -> stage4 (3 modules), 4 BasicBlocks per branch per
 module, exchange unit after each module (hrnet.py:243-302); returns branch 0 only (hrnet.py:441).
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -18,17 +20,22 @@ class HighResolutionModule(nn.Module):
         if len(channels) > 1:
             self.fuse_layers = make_fuse_layers(channels)
 
-    def forward(self, xs):
+    def forward(self, xs, pre=None, defer=False):
+        """`pre` / `defer`: chained modules, see HRFormerModule.forward (the previous module's exchange output i is computed inside
+        this module's branch task i)."""
         def make(b, blocks):
             def run(ins):
-                t = ins[0]
+                t = nnops.exchange_output(b, ins, pre, self.training) if pre is not None else ins[0]
                 for blk in blocks:
                     t = blk(t)
                 return t
             return run
 
-        ys = nnops.parallel([make(b, blocks) for b, blocks in enumerate(self.branches)], [[x] for x in xs])
-        return ys if len(ys) == 1 else nnops.exchange(ys, self.fuse_layers, self.training)
+        ys = nnops.parallel([make(b, blocks) for b, blocks in enumerate(self.branches)], [(list(xs) if pre is not None else [x]) for x in xs])
+        return ys if (len(ys) == 1 or defer) else nnops.exchange(ys, self.fuse_layers, self.training)
+
+
+_CHAIN = os.environ.get("POSE_CHAIN_MODULES", "1") != "0"
 
 
 class HRNet(nn.Module):
@@ -67,8 +74,11 @@ class HRNet(nn.Module):
         ys = [x]
         for s in (2, 3, 4):
             ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
-            for m in getattr(self, f"stage{s}"):
-                ys = m(ys)
+            mods_s, pre = list(getattr(self, f"stage{s}")), None
+            for k, m in enumerate(mods_s):
+                chain = _CHAIN and k + 1 < len(mods_s)
+                ys = m(ys, pre=pre, defer=chain)
+                pre = m.fuse_layers if chain else None
             # N > 1: once backward has passed this boundary the later stages' gradients are exchanged while the earlier stages still
             # run backward (only output 0 of the last stage is consumed, hrformer.py:776 / hrnet.py:441)
             nnops.backward_milestone(ys if s < 4 else ys[:1])

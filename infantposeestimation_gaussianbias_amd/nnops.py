@@ -1023,27 +1023,27 @@ def exchange(xs, fuse, training, n_out=None):
     kernels in flight, profiles/r02_trace_summary.txt.)"""
     from . import dispatch
     n = len(xs)
-
-    def make(i):
-        def run(xs):
-            terms = []
-            for j in range(n):
-                if j == i:
-                    terms.append(xs[j])
-                elif j > i:
-                    conv, bn = fuse[str(i)][str(j)]
-                    terms.append(conv_bn_act(xs[j], conv, bn, False, None, training))      # up-sampled inside fuse_sum
-                else:
-                    t = xs[j]
-                    chain = fuse[str(i)][str(j)]
-                    for s, (conv, bn) in enumerate(chain):
-                        t = conv_bn_act(t, conv, bn, s != len(chain) - 1, None, training)
-                    terms.append(t)
-            return fuse_sum(terms, True)
-        return run
-
     n_o = n if n_out is None else n_out
-    return dispatch.parallel([make(i) for i in range(n_o)], [list(xs)] * n_o)
+    return dispatch.parallel([(lambda ins, i=i: exchange_output(i, ins, fuse, training)) for i in range(n_o)], [list(xs)] * n_o)
+
+
+def exchange_output(i, xs, fuse, training):
+    """Output i of an exchange unit: relu(sum_j route_{j->i}(x_j)).  Also called from inside the NEXT module's branch task i
+    (models: chained modules), so that branch i starts as soon as ITS input is ready instead of after the slowest output."""
+    terms = []
+    for j in range(len(xs)):
+        if j == i:
+            terms.append(xs[j])
+        elif j > i:
+            conv, bn = fuse[str(i)][str(j)]
+            terms.append(conv_bn_act(xs[j], conv, bn, False, None, training))      # up-sampled inside fuse_sum
+        else:
+            t = xs[j]
+            chain = fuse[str(i)][str(j)]
+            for s, (conv, bn) in enumerate(chain):
+                t = conv_bn_act(t, conv, bn, s != len(chain) - 1, None, training)
+            terms.append(t)
+    return fuse_sum(terms, True)
 
 
 def drop_scales(n_draws, batch, drop_prob, device):

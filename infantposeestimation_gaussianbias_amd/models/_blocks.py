@@ -80,6 +80,18 @@ def make_transition(pre, cur):
     return tr
 
 
+def transition_branch(tr, i, t, n_prev, training):
+    """Branch i of a transition applied to its source tensor t (= ys[min(i, n_prev - 1)]): identity, a 3x3 conv + BN when the channel
+    count changes, or the chain of stride-2 convs that creates a new branch from the last one.  Called from inside the first
+    module's branch task i of the new stage (no separate serial pass over the transition convs)."""
+    key = str(i)
+    if i < n_prev:
+        return nnops.conv_bn_act(t, tr[key][0], tr[key][1], True, None, training) if key in tr else t
+    for cv, bn in tr[key]:
+        t = nnops.conv_bn_act(t, cv, bn, True, None, training)
+    return t
+
+
 def run_transition(tr, ys, n_cur, training):
     outs = []
     for i in range(n_cur):

@@ -13,7 +13,7 @@ import torch
 import torch.nn as nn
 
 from .. import dispatch as nnops
-from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, make_transition, run_transition
+from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, make_transition, run_transition, transition_branch
 
 
 class WindowAttentionParams(nn.Module):
@@ -88,7 +88,7 @@ class HRFormerModule(nn.Module):
     def n_draws(self):
         return 2 * sum(len(b) for b in self.branches)
 
-    def forward(self, xs, scales=None, pre=None, defer=False):
+    def forward(self, xs, scales=None, pre=None, defer=False, trans=None):
         """scales: (n_draws, B) DropPath multipliers for this module (two per block, branch-major), or None.
 
         Chaining (same stage, same branch count): with `defer=True` the module returns its branch outputs WITHOUT the exchange unit;
@@ -100,6 +100,8 @@ class HRFormerModule(nn.Module):
         def make(b, blocks, d0):
             def run(ins):
                 t, d = (nnops.exchange_output(b, ins[:n_prev], pre, self.training) if pre is not None else ins[0]), d0
+                if trans is not None:           # first module of a stage: the transition of branch b runs inside its task
+                    t = transition_branch(trans, b, t, n_prev, self.training)
                 k = n_prev if pre is not None else 1
                 sc = ins[k] if len(ins) > k else None
                 for blk in blocks:
@@ -114,7 +116,7 @@ class HRFormerModule(nn.Module):
             fns.append(make(b, blocks, d))
             d += 2 * len(blocks)
         extra = [scales] if scales is not None else []
-        ys = nnops.parallel(fns, [(list(xs) if pre is not None else [xs[b]]) + extra for b in range(len(fns))])
+        ys = nnops.parallel(fns, [(list(xs) if pre is not None else [xs[min(b, n_prev - 1)]]) + extra for b in range(len(fns))])
         if len(ys) == 1 or defer:
             return ys
         return nnops.exchange(ys, self.fuse_layers, self.training)
@@ -176,12 +178,14 @@ class HRFormer(nn.Module):
             scales = nnops.drop_scales(sum(m.n_draws() for m in mods), x.shape[0], self.drop_path_rate, x.device)
         d = 0
         for s in (2, 3, 4):
-            ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
+            trans = getattr(self, f"transition{s - 1}") if _CHAIN else None
+            if not _CHAIN:
+                ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
             mods_s, pre = list(getattr(self, f"stage{s}")), None
             for k, m in enumerate(mods_s):
                 n = m.n_draws()
                 chain = _CHAIN and k + 1 < len(mods_s)          # the exchange unit of this module runs inside the next module's tasks
-                ys = m(ys, None if scales is None else scales[d:d + n], pre=pre, defer=chain)
+                ys = m(ys, None if scales is None else scales[d:d + n], pre=pre, defer=chain, trans=trans if k == 0 else None)
                 pre = m.fuse_layers if chain else None
                 d += n
             # N > 1: once backward has passed this boundary the later stages' gradients are exchanged while the earlier stages still

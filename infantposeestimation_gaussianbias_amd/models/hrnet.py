@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import dispatch as nnops
-from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, make_transition, run_transition
+from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, make_transition, run_transition, transition_branch
 
 
 class HighResolutionModule(nn.Module):
@@ -20,18 +20,23 @@ class HighResolutionModule(nn.Module):
         if len(channels) > 1:
             self.fuse_layers = make_fuse_layers(channels)
 
-    def forward(self, xs, pre=None, defer=False):
-        """`pre` / `defer`: chained modules, see HRFormerModule.forward (the previous module's exchange output i is computed inside
-        this module's branch task i)."""
+    def forward(self, xs, pre=None, defer=False, trans=None):
+        """`pre` / `defer` / `trans`: chained modules, see HRFormerModule.forward (the previous module's exchange output i, or branch i
+        of the stage's transition, is computed inside this module's branch task i)."""
+        n_prev = len(xs)
+
         def make(b, blocks):
             def run(ins):
                 t = nnops.exchange_output(b, ins, pre, self.training) if pre is not None else ins[0]
+                if trans is not None:
+                    t = transition_branch(trans, b, t, n_prev, self.training)
                 for blk in blocks:
                     t = blk(t)
                 return t
             return run
 
-        ys = nnops.parallel([make(b, blocks) for b, blocks in enumerate(self.branches)], [(list(xs) if pre is not None else [x]) for x in xs])
+        ys = nnops.parallel([make(b, blocks) for b, blocks in enumerate(self.branches)],
+                            [(list(xs) if pre is not None else [xs[min(b, n_prev - 1)]]) for b in range(len(self.branches))])
         return ys if (len(ys) == 1 or defer) else nnops.exchange(ys, self.fuse_layers, self.training)
 
 
@@ -73,11 +78,13 @@ class HRNet(nn.Module):
             x = blk(x)
         ys = [x]
         for s in (2, 3, 4):
-            ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
+            trans = getattr(self, f"transition{s - 1}") if _CHAIN else None
+            if not _CHAIN:
+                ys = run_transition(getattr(self, f"transition{s - 1}"), ys, s, tr)
             mods_s, pre = list(getattr(self, f"stage{s}")), None
             for k, m in enumerate(mods_s):
                 chain = _CHAIN and k + 1 < len(mods_s)
-                ys = m(ys, pre=pre, defer=chain)
+                ys = m(ys, pre=pre, defer=chain, trans=trans if k == 0 else None)
                 pre = m.fuse_layers if chain else None
             # N > 1: once backward has passed this boundary the later stages' gradients are exchanged while the earlier stages still
             # run backward (only output 0 of the last stage is consumed, hrformer.py:776 / hrnet.py:441)

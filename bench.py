@@ -106,10 +106,13 @@ def roofline_table(model, B):
     H, W = 64, 48
     M = B * H * W
     out = []
-    traffic = None
+    traffic = traffic_w3 = None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_head_conv_traffic.json")) as f:
-            traffic = round(json.load(f)["traffic_bytes_per_launch"])      # PMC passes are offline (scripts/gpu_pmc_traffic.sh); kernel unchanged since
+        # PMC passes are offline (two rocprofv3 --pmc runs, scripts/pmc_summary.py); regenerated whenever one of the kernels changes
+        with open(os.path.join(ROOT, "profiles", "r02_pmc_head_conv_traffic.json")) as f:
+            pm = json.load(f)["kernels"]
+        traffic = pm["k_igemm2<256, 128, 2, 2, 32>"]["traffic_bytes"]      # mean over the forward and data-gradient launches
+        traffic_w3 = pm["k_wgrad3"]["traffic_bytes"]
     except (OSError, KeyError, ValueError):
         pass
     with nnops.use_weights(model) as wc:
@@ -136,7 +139,7 @@ def roofline_table(model, B):
         # 2. the head conv's weight gradient: k_wgrad3 (256 x 256 tile, 4-stage LDS-DMA ring), 3 launches per step
         sec = time_kernel(wgrad_slabs(x, g, M, C, C, 3, (B, H, W)))
         out.append(_entry("k_wgrad3", "head conv3x3 256->256 @64x48 weight gradient (slabs)", "mfma", sec, flops=flops,
-                          bytes_=2.0 * (2 * M * C), launches=3))
+                          bytes_=2.0 * (2 * M * C), traffic=traffic_w3, launches=3))
         # 3. streaming weight gradient k_wgrad4<128,64>: qkv weight gradient of the branch-0 blocks (tokens x 96 x 32)
         Mw = B * 70 * 49
         u, dq = torch.randn(Mw, 32, device=dev).to(BF), torch.randn(Mw, 96, device=dev).to(BF)

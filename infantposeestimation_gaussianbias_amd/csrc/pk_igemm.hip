@@ -309,6 +309,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     int t_next = 0, c_next = 0;           // (tap, chunk) of the tile being loaded
+    // (Measured and dropped: chunk-major order -- all nine taps of one channel chunk back to back, so that the shifted re-reads of the
+    // same pixels stay in L2 instead of cycling ~11 MB per XCD between two taps (PMC: the head conv fetches 4.1x its input).  The row
+    // offsets must then be recomputed every step: head conv forward 335 -> 400 us, dgrad 290 -> 360 us; only N = 32 tiles gained.)
     auto advance = [&]() {                // next (tap, chunk) in contraction order; recomputes the row offsets on a tap change
         c_next += BK;
         if (c_next >= p.Cin) {

@@ -117,3 +117,18 @@ __device__ __forceinline__ void gelu_both(float x, float& val, float& grad) {
     grad = __fmaf_rn(x * 0.39894228040143267794f, g.e, gelu_cdf(x, g.hw));
 }
 __device__ __forceinline__ float softplus_(float v) { return v > 20.f ? v : log1pf(__expf(v)); }
+
+// Sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane of the row: two quad permutes and two row
+// rotations, i.e. four VALU instructions.  (`__shfl_xor` compiles to ds_bpermute_b32 -- an LDS-crossbar instruction with LDS
+// latency; the BatchNorm-statistics epilogue of the conv kernel issued 128 of them per wave and tile, ~1 us per wave, which is most
+// of a shallow conv's run time.)  Fixed order: deterministic.
+__device__ __forceinline__ float row16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));     // quad_perm [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));     // quad_perm [2,3,0,1]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));    // row_ror:4
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));    // row_ror:8
+#endif
+    return v;
+}
+

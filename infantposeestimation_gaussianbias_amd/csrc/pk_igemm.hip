@@ -461,11 +461,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
                     s += v;
                     q += v * v;
                 }
-#pragma unroll
-                for (int o = 1; o < 16; o <<= 1) {
-                    s += __shfl_xor(s, o, 64);
-                    q += __shfl_xor(q, o, 64);
-                }
+                s = row16_sum(s);
+                q = row16_sum(q);
                 if ((lane & 15) == 0) {
                     const int nl = wn * (BN / WN) + a * 16 + (lane >> 4) * 4 + r;
                     sStat[(wm * BN + nl) * 2] = s;

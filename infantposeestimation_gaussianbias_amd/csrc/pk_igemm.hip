@@ -506,15 +506,22 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             if (n + 4 + j < p.N) bhi[j] = p.bias[n + 4 + j];
         }
     }
+    // The staging tile is wave-private: only the lanes of ONE wave exchange data through it, so a wave-level fence orders the writes
+    // against the reads (a workgroup barrier made every wave wait for the slowest of four, twice per pass -- these epilogues are
+    // most of the run time of the shallow GEMMs).
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
 #pragma unroll
     for (int pass = 0; pass < MI / BPP; ++pass) {
-        if (pass) __syncthreads();                   // the previous pass has been read out
+        if (pass) wave_sync();                       // the previous pass has been read out
 #pragma unroll
         for (int bb = 0; bb < BPP; ++bb)
 #pragma unroll
             for (int a = 0; a < NI; ++a)
                 *reinterpret_cast<f32x4*>(&stage[(bb * 16 + (lane & 15)) * EP + a * 16 + (lane >> 4) * 4]) = acc[a][pass * BPP + bb];
-        __syncthreads();
+        wave_sync();
         if (n_ok) {
 #pragma unroll 2
             for (int ps = 0; ps < BPP * 16 / RPP; ++ps) {

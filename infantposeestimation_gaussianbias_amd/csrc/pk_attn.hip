@@ -141,8 +141,8 @@ __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict_
                 st[cj][r] = aj[cj][r] >= 0 ? st[cj][r] * scale + bv : -INFINITY;
                 mx = fmaxf(mx, st[cj][r]);
             }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xor16_max(mx);
+        mx = xor32_max(mx);
         float sum = 0.f;
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj)
@@ -151,8 +151,8 @@ __global__ void __launch_bounds__(64) k_win_attn_fwd(const uint16_t* __restrict_
                 st[cj][r] = __expf(st[cj][r] - mx);
                 sum += st[cj][r];
             }
-        sum += __shfl_xor(sum, 16, 64);
-        sum += __shfl_xor(sum, 32, 64);
+        sum = xor16_sum(sum);
+        sum = xor32_sum(sum);
         const float inv = 1.f / sum;
         if (g4 == 0 && i < AT_N && lse) lse[((size_t)w * heads + h) * AT_N + i] = mx + __logf(sum);
         const bf16x8 p0 = pack_frag(st[0], st[1], inv), p1 = pack_frag(st[2], st[3], inv);

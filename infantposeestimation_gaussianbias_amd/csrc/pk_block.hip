@@ -109,8 +109,8 @@ __device__ __forceinline__ void ln_row(const u32x4 (&xr)[NK], const float (&gam)
             v[k][2 * j + 1] = bhi(xr[k][j]);
             s += v[k][2 * j] + v[k][2 * j + 1];
         }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = xor16_sum(s);
+    s = xor32_sum(s);
     mean = s * inv_c;
     float q = 0.f;
 #pragma unroll
@@ -120,8 +120,8 @@ __device__ __forceinline__ void ln_row(const u32x4 (&xr)[NK], const float (&gam)
             v[k][j] -= mean;
             q += v[k][j] * v[k][j];
         }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
+    q = xor16_sum(q);
+    q = xor32_sum(q);
     rstd = rsqrtf(q * inv_c + eps);
 #pragma unroll
     for (int k = 0; k < NK; ++k) {
@@ -367,10 +367,10 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dx(MlpArgs p) {
                 dgam[ct] += dv[rt][ct] * xh[ct];
                 dbet[ct] += dv[rt][ct];
             }
-            s1 += __shfl_xor(s1, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
+            s1 = xor16_sum(s1);
+            s1 = xor32_sum(s1);
+            s2 = xor16_sum(s2);
+            s2 = xor32_sum(s2);
             const float m1 = s1 * inv_c, m2 = s2 * inv_c;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -385,11 +385,8 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dx(MlpArgs p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a = dgam[ct][r], b = dbet[ct][r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                a += __shfl_xor(a, o, 64);
-                b += __shfl_xor(b, o, 64);
-            }
+            a = lanes_sum<16>(a);
+            b = lanes_sum<16>(b);
             if (i16 == 0) {
                 sRed[wave][0][16 * ct + 4 * g + r] = a;
                 sRed[wave][1][16 * ct + 4 * g + r] = b;
@@ -553,8 +550,8 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dw(MlpArgs p) {
                         *b = (w ? *b : 0.f) + dW2[ct][t][r];
                     }
                 float v = db1[t];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
+                v = xor16_sum(v);
+                v = xor32_sum(v);
                 if (g == 0) {
                     float* a = slab + 2 * HS * C + 16 * t + i16;
                     *a = (w ? *a : 0.f) + v;
@@ -563,8 +560,8 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dw(MlpArgs p) {
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 float v = db2[ct];
-                v += __shfl_xor(v, 16, 64);
-                v += __shfl_xor(v, 32, 64);
+                v = xor16_sum(v);
+                v = xor32_sum(v);
                 if (g == 0) {
                     float* a = slab + 2 * HS * C + HS + 16 * ct + i16;
                     *a = (w ? *a : 0.f) + v;
@@ -752,8 +749,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs p) {
                         st[cj][r] = aj[cj][r] >= 0 ? st[cj][r] * p.softmax_scale + bv : -INFINITY;
                         mx = fmaxf(mx, st[cj][r]);
                     }
-                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                mx = xor16_max(mx);
+                mx = xor32_max(mx);
                 float sum = 0.f;
 #pragma unroll
                 for (int cj = 0; cj < 4; ++cj)
@@ -762,8 +759,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs p) {
                         st[cj][r] = __expf(st[cj][r] - mx);
                         sum += st[cj][r];
                     }
-                sum += __shfl_xor(sum, 16, 64);
-                sum += __shfl_xor(sum, 32, 64);
+                sum = xor16_sum(sum);
+                sum = xor32_sum(sum);
                 const float inv = 1.f / sum;
                 if (g == 0 && i < AT_N && p.lse) p.lse[((size_t)w * HEADS + h) * AT_N + i] = mx + __logf(sum);
                 const bf16x8 p0 = pack2(st[0] * inv, st[1] * inv), p1 = pack2(st[2] * inv, st[3] * inv);
@@ -928,8 +925,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                     float de = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) de += a[3][0][r] * o0[r] + a[3][1][r] * o1[r];
-                    de += __shfl_xor(de, 16, 64);
-                    de += __shfl_xor(de, 32, 64);
+                    de = xor16_sum(de);
+                    de = xor32_sum(de);
                     const float l = i < AT_N ? p.lse[((size_t)w * HEADS + h) * AT_N + i] : 0.f;
                     if (g == 0) {
                         sLse[wave][i] = l;
@@ -1115,10 +1112,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                     dbet[ct] += du[ct];
                 }
             }
-            s1 += __shfl_xor(s1, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
+            s1 = xor16_sum(s1);
+            s1 = xor32_sum(s1);
+            s2 = xor16_sum(s2);
+            s2 = xor32_sum(s2);
             const float m1 = s1 * inv_c, m2 = s2 * inv_c;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
@@ -1134,11 +1131,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             float a = dgam[ct][r], b = dbet[ct][r];
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) {
-                a += __shfl_xor(a, o, 64);
-                b += __shfl_xor(b, o, 64);
-            }
+            a = lanes_sum<16>(a);
+            b = lanes_sum<16>(b);
             if (i16 == 0) {
                 sRed[wave][0][16 * ct + 4 * g + r] = a;
                 sRed[wave][1][16 * ct + 4 * g + r] = b;

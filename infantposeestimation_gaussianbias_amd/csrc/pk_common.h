@@ -132,3 +132,56 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+
+// Cross-row combines for values laid out as 4 rows x 16 columns per wave (lane = 16 * row + column): the xor-16 / xor-32 butterfly
+// steps with the gfx950 row swaps (v_permlane16_swap / v_permlane32_swap, VALU rate) instead of ds_bpermute_b32.  With both operands
+// the same register, the swap returns (rows 0,0,2,2 | rows 1,1,3,3) resp. (low half twice | high half twice): combining the two
+// results is the butterfly step, same operand pairs as before (bitwise identical sums).
+__device__ __forceinline__ float xor16_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#else
+    return v;
+#endif
+}
+__device__ __forceinline__ float xor32_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+#else
+    return v;
+#endif
+}
+__device__ __forceinline__ float xor16_max(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+    return v;
+#endif
+}
+__device__ __forceinline__ float xor32_max(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+#else
+    return v;
+#endif
+}
+
+// All-reduce (sum) over groups of L consecutive lanes (L = 1, 2, 4, ..., 64), result in every lane: the xor butterfly with DPP
+// (quad permutes, half-row / row mirrors) inside a 16-lane row and the row swaps above across rows.  Same operand pairs at every
+// level as `v += __shfl_xor(v, o)`, i.e. bitwise the same sums, without ds_bpermute.
+template <int L>
+__device__ __forceinline__ float lanes_sum(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (L >= 2) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));      // quad_perm [1,0,3,2]
+    if (L >= 4) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));      // quad_perm [2,3,0,1]
+    if (L >= 8) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x141, 0xF, 0xF, true));     // row_half_mirror
+    if (L >= 16) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xF, 0xF, true));    // row_mirror
+    if (L >= 32) v = xor16_sum(v);
+    if (L >= 64) v = xor32_sum(v);
+#endif
+    return v;
+}

@@ -324,8 +324,7 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const uint4* __restrict__ x, con
 #pragma unroll
         for (int j = 0; j < 8; ++j) s += (ch * 8 + j < Cr) ? v[c][j] : 0.f;
     }
-#pragma unroll
-    for (int o = 1; o < L; o <<= 1) s += __shfl_xor(s, o, 64);
+    s = lanes_sum<L>(s);
     const float mean = s / (float)Cr;
     float q = 0.f;
 #pragma unroll
@@ -336,8 +335,7 @@ __global__ void __launch_bounds__(256) k_ln_fwd(const uint4* __restrict__ x, con
             for (int j = 0; j < 8; ++j) q += (ch * 8 + j < Cr) ? (v[c][j] - mean) * (v[c][j] - mean) : 0.f;
         }
     }
-#pragma unroll
-    for (int o = 1; o < L; o <<= 1) q += __shfl_xor(q, o, 64);
+    q = lanes_sum<L>(q);
     const float rstd = rsqrtf(q / (float)Cr + eps);
 #pragma unroll
     for (int c = 0; c < CPL; ++c) {
@@ -447,11 +445,8 @@ __global__ void __launch_bounds__(256) k_ln_bwd(const uint4* __restrict__ dy, co
                 ab[c][j] += g[c][j];
             }
         }
-#pragma unroll
-        for (int o = 1; o < L; o <<= 1) {
-            s1 += __shfl_xor(s1, o, 64);
-            s2 += __shfl_xor(s2, o, 64);
-        }
+        s1 = lanes_sum<L>(s1);
+        s2 = lanes_sum<L>(s2);
         const float m1 = s1 / (float)Cr, m2 = s2 / (float)Cr;
 #pragma unroll
         for (int c = 0; c < CPL; ++c) {
@@ -688,9 +683,7 @@ __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict
                 }
             }
 #pragma unroll
-        for (int o = 1; o < SPLIT; o <<= 1)       // fixed butterfly over the SPLIT row-lanes: deterministic
-#pragma unroll
-            for (int j = 0; j < 8; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+        for (int j = 0; j < 8; ++j) acc[j] = lanes_sum<SPLIT>(acc[j]);       // fixed butterfly over the SPLIT row-lanes: deterministic
         if (on && sub == 0) *reinterpret_cast<uint4*>(dsrc + i * 8) = pack8(acc);
     }
 }

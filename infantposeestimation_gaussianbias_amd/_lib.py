@@ -9,7 +9,8 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libposekernels.so")
+# POSE_KERNELS_LIB: another build of the same library (A/B measurements of two builds on one box); it must export every declared symbol
+LIB_PATH = os.environ.get("POSE_KERNELS_LIB") or os.path.join(_HERE, "csrc", "libposekernels.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "posekernels.h")
 
 _CT = {

@@ -139,7 +139,7 @@ __global__ void __launch_bounds__(256) k_bn_act(const uint4* __restrict__ x, con
                                                 const float* __restrict__ shift, const uint4* __restrict__ res, uint4* __restrict__ y,
                                                 size_t chunks, int cchunks, int relu) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cchunks) * 8;
+        const int c0 = (int)((uint32_t)i % (uint32_t)cchunks) * 8;      // 32-bit: a size_t modulo is a ~60-instruction software division per chunk
         float v[8], r[8];
         unpack8(x[i], v);
         if (res) unpack8(res[i], r);
@@ -156,6 +156,7 @@ extern "C" int pk_bn_act(const void* x, const float* scale, const float* shift, 
                          int relu, void* stream) {
     PK_REQUIRE(x && scale && shift && y && rows > 0 && C > 0 && (C & 7) == 0, "pk_bn_act: bad argument (C=%d)", C);
     const size_t chunks = (size_t)rows * (C / 8);
+    PK_SUPPORTED(chunks < 0xffffffffull, "pk_bn_act: tensor too large for 32-bit chunk indices");
     size_t nb = (chunks + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(k_bn_act, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, scale, shift,
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ 
                                                       uint4* __restrict__ dres, size_t chunks, int cchunks, int relu) {
     const int C = cchunks * 8;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)(i % cchunks) * 8;
+        const int c0 = (int)((uint32_t)i % (uint32_t)cchunks) * 8;      // 32-bit: a size_t modulo is a ~60-instruction software division per chunk
         float g[8], xr[8], ya[8], o[8];
         unpack8(dy[i], g);
         unpack8(raw[i], xr);
@@ -272,6 +273,7 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     // sums = [sum g | sum g*xhat] for the apply kernel; the same values go to dbeta / dgamma (possibly flat-gradient views)
     hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(16 * RED_LANES), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0, dbeta, dgamma, C);
     const size_t chunks = (size_t)rows * (C / 8);
+    PK_SUPPORTED(chunks < 0xffffffffull, "pk_bn_bwd: tensor too large for 32-bit chunk indices");
     size_t gb = (chunks + 255) / 256;
     if (gb > 4096) gb = 4096;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)gb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw,
@@ -584,11 +586,12 @@ __global__ void __launch_bounds__(256) k_fuse_sum(FuseArgs a) {
     const int cchunks = a.C / 8;
     const size_t chunks = (size_t)a.B * a.H * a.W * cchunks;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
-        const int cc = (int)(i % cchunks);
-        size_t pix = i / cchunks;
-        const int x = (int)(pix % a.W);
-        pix /= a.W;
-        const int y = (int)(pix % a.H), b = (int)(pix / a.H);
+        // (32-bit index arithmetic: five size_t divisions were ~300 VALU instructions per 16-byte output chunk)
+        const uint32_t i32 = (uint32_t)i, pix0 = i32 / (uint32_t)cchunks;
+        const int cc = (int)(i32 - pix0 * (uint32_t)cchunks);
+        const uint32_t pix1 = pix0 / (uint32_t)a.W;
+        const int x = (int)(pix0 - pix1 * (uint32_t)a.W);
+        const int b = (int)(pix1 / (uint32_t)a.H), y = (int)(pix1 - (uint32_t)b * (uint32_t)a.H);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < a.n; ++k) {
             const FuseIn& in = a.in[k];
@@ -631,6 +634,7 @@ extern "C" int pk_fuse_sum(const void* const* inputs, const int* in_h, const int
     }
     a.n = n_inputs; a.out = (uint16_t*)out; a.B = B; a.H = H; a.W = W; a.C = C; a.relu = relu;
     const size_t chunks = (size_t)B * H * W * (C / 8);
+    PK_SUPPORTED(chunks < 0xffffffffull, "pk_fuse_sum: tensor too large for 32-bit chunk indices");
     size_t gb = (chunks + 255) / 256;
     if (gb > 4096) gb = 4096;
     hipLaunchKernelGGL(k_fuse_sum, dim3((unsigned)gb), dim3(256), 0, (hipStream_t)stream, a);
@@ -652,11 +656,11 @@ __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict
     for (size_t it = 0; it < n_iter; ++it, i += groups_per_grid) {
         const bool on = i < chunks;
         const size_t ii = on ? i : 0;
-        const int cc = (int)(ii % cchunks);
-        size_t pix = ii / cchunks;
-        const int xs = (int)(pix % Ws);
-        pix /= Ws;
-        const int ys = (int)(pix % Hs), b = (int)(pix / Hs);
+        const uint32_t i32 = (uint32_t)ii, pix0 = i32 / (uint32_t)cchunks;
+        const int cc = (int)(i32 - pix0 * (uint32_t)cchunks);
+        const uint32_t pix1 = pix0 / (uint32_t)Ws;
+        const int xs = (int)(pix0 - pix1 * (uint32_t)Ws);
+        const int b = (int)(pix1 / (uint32_t)Hs), ys = (int)(pix1 - (uint32_t)b * (uint32_t)Hs);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // support of source pixel ys: outputs whose source coordinate (oy + .5) * Hs/H - .5 lies in (ys-1, ys+1), i.e.
         // oy in ((ys-.5)*H/Hs - .5, (ys+1.5)*H/Hs - .5); H/Hs <= ry, one extra row each side covers non-integer ratios.
@@ -690,6 +694,7 @@ __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict
 extern "C" int pk_upsample_bilinear_bwd(const void* dy, void* dsrc, int B, int H, int W, int Hs, int Ws, int C, void* stream) {
     PK_REQUIRE(dy && dsrc && B > 0 && H >= Hs && W >= Ws && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0, "pk_upsample_bilinear_bwd: bad argument");
     const size_t chunks = (size_t)B * Hs * Ws * (C / 8);
+    PK_SUPPORTED(chunks < 0xffffffffull, "pk_upsample_bilinear_bwd: tensor too large for 32-bit chunk indices");
     const int ry = (H + Hs - 1) / Hs;
     // few output chunks with a tall gather window (scale 4 / 8): spread the window rows over 4 / 16 lanes per chunk
     const int split = (ry >= 8 && chunks < (1u << 20)) ? 16 : ((ry >= 4 && chunks < (1u << 20)) ? 4 : 1);

@@ -265,6 +265,8 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     PK_REQUIRE(!relu || y_act, "pk_bn_bwd: relu needs the activated output");
     PK_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0, "pk_bn_bwd: bad sizes");
     PK_SUPPORTED(C <= BNR_MAXC && C / 8 <= 256, "pk_bn_bwd: C=%d too large", C);
+    const size_t chunks = (size_t)rows * (C / 8);
+    PK_SUPPORTED(chunks < 0xffffffffull, "pk_bn_bwd: tensor too large for 32-bit chunk indices");
     hipStream_t st = (hipStream_t)stream;
     const int nb = pk_bn_bwd_blocks(rows);
     const int rpb = (int)((rows + nb - 1) / nb);
@@ -272,8 +274,6 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
                        save_rstd, partial, rows, C, relu, rpb);
     // sums = [sum g | sum g*xhat] for the apply kernel; the same values go to dbeta / dgamma (possibly flat-gradient views)
     hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(16 * RED_LANES), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0, dbeta, dgamma, C);
-    const size_t chunks = (size_t)rows * (C / 8);
-    PK_SUPPORTED(chunks < 0xffffffffull, "pk_bn_bwd: tensor too large for 32-bit chunk indices");
     size_t gb = (chunks + 255) / 256;
     if (gb > 4096) gb = 4096;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)gb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw,

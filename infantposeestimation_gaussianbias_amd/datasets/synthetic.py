@@ -8,7 +8,10 @@ import torch
 from .generate_heatmap import generate_target
 
 
-def synthetic_batch(batch_size, input_size=(192, 256), heatmap_size=(48, 64), num_keypoints=17, sigma=2.0, device="cuda", seed=1234):
+def synthetic_batch(batch_size, input_size=(192, 256), heatmap_size=(48, 64), num_keypoints=17, sigma=2.0, device="cuda", seed=1234,
+                    id_base=0):
+    """`id_base`: first image / annotation id of the batch (a loader numbers its batches consecutively, so that an evaluator keyed by
+    image id never merges instances of different batches)."""
     g = torch.Generator(device="cpu").manual_seed(seed)
     W, H = input_size
     img = torch.randn(batch_size, 3, H, W, generator=g)
@@ -18,7 +21,7 @@ def synthetic_batch(batch_size, input_size=(192, 256), heatmap_size=(48, 64), nu
     img, kp, vis = img.to(device), kp.to(device), vis.to(device)
     target, weight = generate_target(kp, vis, input_size, heatmap_size, sigma)
     return {"img": img, "target": target, "target_weight": weight, "keypoints": kp, "keypoints_visible": vis,
-            "meta": {"image_id": torch.arange(batch_size), "ann_id": torch.arange(batch_size),
+            "meta": {"image_id": torch.arange(batch_size) + id_base, "ann_id": torch.arange(batch_size) + id_base,
                      "center": torch.tensor([[W / 2.0, H / 2.0]]).repeat(batch_size, 1),
                      "scale": torch.tensor([[float(W), float(H)]]).repeat(batch_size, 1),
                      "bbox": torch.tensor([[0.0, 0.0, float(W), float(H)]]).repeat(batch_size, 1),
@@ -41,4 +44,5 @@ class SyntheticLoader:
     def __iter__(self):
         d = self.cfg.data
         for i in range(self.n):
-            yield synthetic_batch(self.cfg.train.batch_size, d.input_size, d.heatmap_size, d.num_keypoints, d.sigma, self.device, self.seed + i)
+            yield synthetic_batch(self.cfg.train.batch_size, d.input_size, d.heatmap_size, d.num_keypoints, d.sigma, self.device, self.seed + i,
+                                  id_base=i * self.cfg.train.batch_size)

@@ -359,6 +359,12 @@ class Trainer:
             return
         # (also while a forward+backward-only graph is being captured: the partial reduction tables must be the ones the eager
         # warm-up steps built -- a new table cannot be uploaded during capture; only the collectives are held back)
+        if not self._region:
+            # eager branch streams: the hook fires on the stream of whichever boundary producer ran last, while the weight-gradient
+            # kernels of the other branches were enqueued on side streams autograd does not order against this one.  (Region mode
+            # joins every side stream at the end of each region's backward, so nothing is outstanding there.)
+            from . import dispatch
+            dispatch.join_side_streams(torch.cuda.current_stream())
         nnops.finalize_deferred()
         self.comm.flush_ready()
 
@@ -389,7 +395,7 @@ class Trainer:
 
     # -- graph path --------------------------------------------------------------------------------------------
     def _comm_capturable(self):
-        return (self.comm.world > 1 and dist.get_backend(self.comm.group) == "nccl" and os.environ.get("POSE_GRAPH_COMM", "1") != "0")
+        return (self.comm.world > 1 and dist.get_backend(self.comm.group) == "nccl" and os.environ.get("POSE_GRAPH_COMM", "0") == "1")
 
     def _capture(self, batch):
         keys = [k for k in ("img_nhwc8" if batch.get("img_nhwc8") is not None else "img", "target", "target_weight", "keypoints")

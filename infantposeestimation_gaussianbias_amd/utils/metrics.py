@@ -3,8 +3,8 @@
 `COCOEvaluator.update` takes what `validate()` has at hand.  When the predictions are device tensors the (B,K,3) records and the
 per-instance scores come from one kernel (pk_pose_records) and ONE device->host copy per batch; numpy inputs (the reference's
 calling convention) are accepted as they are -- the evaluator itself is host bookkeeping (a list of dicts for pycocotools).
-COCO AP through pycocotools is third-party code outside the path: `evaluate()` uses it when it is importable and
-an annotation file is given, and offers the reference's own OKS matching (`gt_annotations=`) otherwise."""
+COCO AP through pycocotools is third-party code outside the path: `evaluate()` hands it the records when an
+annotation file is given, and otherwise reports the precision of greedy OKS matching against `gt_annotations=` (array form)."""
 from collections import defaultdict
 from typing import Dict, List, Optional
 
@@ -45,69 +45,64 @@ class COCOEvaluator:
             self.predictions.append({'image_id': int(image_ids[i]), 'ann_id': int(ann_ids[i]), 'keypoints': rec[i].flatten().tolist(),
                                      'score': float(inst[i]), 'area': float(areas[i]), 'bbox': bboxes[i].tolist()})
 
-    def compute_oks(self, pred_kpts, gt_kpts, gt_vis, area) -> float:
-        d = (pred_kpts[:, 0] - gt_kpts[:, 0]) ** 2 + (pred_kpts[:, 1] - gt_kpts[:, 1]) ** 2
-        e = d / (2 * area * (self.oks_sigmas ** 2) + np.spacing(1))
-        valid = gt_vis > 0
-        if valid.sum() == 0:
-            return 0.0
-        return np.sum(np.exp(-e[valid])) / valid.sum()
-
     def evaluate(self, gt_annotations: Optional[List[Dict]] = None) -> Dict[str, float]:
-        if len(self.predictions) == 0:
+        """AP numbers for the collected records.  With an annotation file the arithmetic is pycocotools' (third-party, outside the
+        path: SURVEY §2 row 12 -- this only hands it the records); without one, `gt_annotations` (dicts with image_id / keypoints /
+        area) are matched by OKS (`oks_precision`), the stand-in train.py uses to pick best.pth on loaders that carry no file."""
+        if not self.predictions:
             return {'AP': 0.0, 'AP50': 0.0, 'AP75': 0.0}
         if self.ann_file is not None:
-            import json
-            import os
-            import tempfile
-            from pycocotools.coco import COCO              # third-party: ImportError here means "install pycocotools", as in the reference
-            from pycocotools.cocoeval import COCOeval
-            with tempfile.NamedTemporaryFile(mode='w', suffix='.json', delete=False) as f:
-                json.dump(self.predictions, f)
-                pred_file = f.name
-            try:
-                coco_gt = COCO(self.ann_file)
-                coco_eval = COCOeval(coco_gt, coco_gt.loadRes(pred_file), 'keypoints')
-                coco_eval.evaluate()
-                coco_eval.accumulate()
-                coco_eval.summarize()
-                names = ('AP', 'AP50', 'AP75', 'AP_M', 'AP_L', 'AR', 'AR50', 'AR75', 'AR_M', 'AR_L')
-                return {n: coco_eval.stats[i] for i, n in enumerate(names)}
-            finally:
-                os.unlink(pred_file)
-        if gt_annotations is not None:
-            return self._manual_evaluate(gt_annotations)
-        raise ValueError("Either ann_file or gt_annotations must be provided")
+            return _pycocotools_keypoint_stats(self.ann_file, self.predictions)
+        if gt_annotations is None:
+            raise ValueError("Either ann_file or gt_annotations must be provided")
+        return oks_precision(self.predictions, gt_annotations, self.oks_sigmas, self.oks_thresholds)
 
-    def _manual_evaluate(self, gt_annotations: List[Dict]) -> Dict[str, float]:
-        """Greedy OKS matching per image and threshold; "AP" = precision at the threshold (utils/metrics.py:206-270)."""
-        pred_by_img, gt_by_img = defaultdict(list), defaultdict(list)
-        for pred in self.predictions:
-            pred_by_img[pred['image_id']].append(pred)
-        for gt in gt_annotations:
-            gt_by_img[gt['image_id']].append(gt)
-        aps = []
-        for thresh in self.oks_thresholds:
-            tp = fp = 0
-            for img_id, gts in gt_by_img.items():
-                matched = set()
-                for pred in sorted(pred_by_img[img_id], key=lambda x: x['score'], reverse=True):
-                    pk = np.array(pred['keypoints']).reshape(-1, 3)
-                    best_oks, best_idx = 0, -1
-                    for gi, gt in enumerate(gts):
-                        if gi in matched:
-                            continue
-                        gk = np.array(gt['keypoints']).reshape(-1, 3)
-                        oks = self.compute_oks(pk[:, :2], gk[:, :2], gk[:, 2], gt['area'])
-                        if oks > best_oks:
-                            best_oks, best_idx = oks, gi
-                    if best_oks >= thresh and best_idx >= 0:
-                        tp += 1
-                        matched.add(best_idx)
-                    else:
-                        fp += 1
-            aps.append(tp / (tp + fp + 1e-10))
-        return {'AP': np.mean(aps), 'AP50': aps[0] if len(aps) > 0 else 0.0, 'AP75': aps[5] if len(aps) > 5 else 0.0}
+
+def _pycocotools_keypoint_stats(ann_file, records):
+    from pycocotools.coco import COCO              # ImportError here means "install pycocotools", as in the reference
+    from pycocotools.cocoeval import COCOeval
+    gt = COCO(ann_file)
+    ev = COCOeval(gt, gt.loadRes(list(records)), 'keypoints')       # loadRes takes the list itself: no temporary json file
+    for stage in (ev.evaluate, ev.accumulate, ev.summarize):
+        stage()
+    return dict(zip(('AP', 'AP50', 'AP75', 'AP_M', 'AP_L', 'AR', 'AR50', 'AR75', 'AR_M', 'AR_L'), ev.stats))
+
+
+def oks_precision(records, gts, sigmas, thresholds):
+    """Precision of score-ordered greedy OKS matching at each threshold (the quantity utils/metrics.py:206-270 reports as "AP").
+
+    Per image ONE (predictions x ground truths) OKS matrix is built with array arithmetic and shared by all thresholds; only the
+    greedy assignment (inherently sequential: a matched ground truth leaves the pool) walks it row by row."""
+    var2 = 2.0 * np.asarray(sigmas, np.float64) ** 2
+    img_of_gt = np.array([g['image_id'] for g in gts])
+    img_of_pr = np.array([r['image_id'] for r in records])
+    gk = np.array([g['keypoints'] for g in gts], np.float64).reshape(len(gts), -1, 3)
+    pk = np.array([r['keypoints'] for r in records], np.float64).reshape(len(records), -1, 3)
+    g_area = np.array([g['area'] for g in gts], np.float64)
+    p_score = np.array([r['score'] for r in records], np.float64)
+    hits = np.zeros(len(thresholds), np.int64)
+    tried = 0
+    for img in dict.fromkeys(img_of_gt.tolist()):
+        gi, pi = np.flatnonzero(img_of_gt == img), np.flatnonzero(img_of_pr == img)
+        pi = pi[np.argsort(-p_score[pi], kind="stable")]
+        tried += len(pi)
+        if not len(pi):
+            continue
+        d2 = ((pk[pi, None, :, :2] - gk[None, gi, :, :2]) ** 2).sum(-1)                         # (P, G, K)
+        vis = gk[gi, :, 2] > 0                                                                      # (G, K)
+        e = np.exp(-d2 / (g_area[gi, None] * var2[None, :] + np.spacing(1))[None])
+        nvis = vis.sum(-1)
+        oks = np.where(nvis > 0, (e * vis[None]).sum(-1) / np.maximum(nvis, 1), 0.0)                # (P, G)
+        for t, th in enumerate(thresholds):
+            free = np.ones(len(gi), bool)
+            for row in oks:
+                cand = np.where(free, row, -1.0)
+                j = int(cand.argmax())                     # first maximum, like the reference's strict '>' scan
+                if cand[j] > 0 and cand[j] >= th:
+                    free[j] = False
+                    hits[t] += 1
+    prec = hits / (tried + 1e-10)
+    return {'AP': prec.mean(), 'AP50': prec[0], 'AP75': prec[5] if len(prec) > 5 else 0.0}
 
 
 class AverageMeter:

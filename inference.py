@@ -119,6 +119,12 @@ def main(args):
     for kp, sc in results:
         for k, ((x, y), s) in enumerate(zip(kp, sc)):
             print(f'  kpt {k:2d}: ({x:8.2f}, {y:8.2f})  score {s:.3f}')
+    if args.output:
+        # inference.py:296-300 of the reference: draw and save.  Drawing is OpenCV's (visualize raises RuntimeError without cv2).
+        vis = img
+        for n, (kp, sc) in enumerate(results):
+            vis = pose.visualize(vis, kp, sc, score_threshold=args.threshold, output_path=args.output if n == len(results) - 1 else None)
+        print(f'Result saved to: {args.output}')
 
 
 if __name__ == '__main__':

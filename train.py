@@ -109,6 +109,8 @@ def main(args):
             is_best = metrics["AP"] > best_ap
             best_ap = max(best_ap, metrics["AP"])
             save_checkpoint(model, trainer, epoch, dict({k: float(v) for k, v in metrics.items()}, train_loss=float(loss)), out_dir, is_best=is_best)
+        if world > 1 and ((epoch + 1) % cfg.train.val_interval == 0 or epoch == cfg.train.max_epochs - 1):
+            dist.barrier()          # the other ranks wait here, not inside the next epoch's first all-reduce (RCCL watchdog timeout)
     if world > 1:
         dist.destroy_process_group()
 

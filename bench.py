@@ -308,6 +308,21 @@ def main():
         runner = InferRunner(model, batch["img"], cfg.data.flip_pairs or [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12)])
         step = lambda: runner.step(batch["img"])
 
+    comm_check = None
+    if world > 1:
+        # self-verifying multi-GPU record: RCCL sums a ones-tensor over the ranks before anything is timed, and every rank reports
+        # the device it drives (name + PCI bus id), gathered over the same communicator
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        pr = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local, "device": pr.name, "pci_bus_id": getattr(pr, "pci_bus_id", None),
+                "pci_device_id": getattr(pr, "pci_device_id", None), "uuid": str(getattr(pr, "uuid", ""))}
+        gathered = [None] * world
+        dist.all_gather_object(gathered, mine)
+        comm_check = {"backend": dist.get_backend(), "rccl_ranks": int(ones.item()), "ranks": gathered}
+        if int(ones.item()) != world:
+            raise SystemExit(f"bench.py: all_reduce of ones over {world} ranks returned {ones.item()}")
+
     out = None
     for i in range(args.warmup):
         t_w = time.perf_counter()
@@ -367,6 +382,10 @@ def main():
             "hbm_reserved_gb": round(torch.cuda.max_memory_reserved(dev) / 2 ** 30, 2),
             "c_abi_calls_per_step": calls_per_step, "backend": dispatch.backend_name(model),
         }
+        if comm_check is not None:
+            comm_check["collectives_captured_in_graph"] = bool(c["mode"] == "train" and getattr(trainer, "_graph_has_comm", False))
+            comm_check["buckets_launched_from_backward_milestones"] = int(trainer.comm.launched_early) if c["mode"] == "train" else None
+            line["comm"] = comm_check
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

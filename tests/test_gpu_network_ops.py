@@ -2,7 +2,9 @@
 
 Inputs and weights are made bf16-representable, the reference is plain PyTorch fp32 on the CPU (or the oracle in
 oracle/nets.py), so the only differences are fp32 accumulation order and the final bf16 rounding of stored outputs:
-tolerance 2e-3 norm-wise where the kernel emits fp32, 8e-3 (= 2 bf16 ulp) where it stores bf16, stated per test.
+tolerance FP32_TOL = 1e-4 norm-wise where the kernel accumulates AND emits fp32 (north_star's 1e-3 with a decade of margin;
+accumulation order alone is ~1e-6, so a partial sum that took a bf16 round trip -- 4e-3 -- cannot hide), 8e-3 (= 2 bf16 ulp) where
+it stores bf16, stated per test.
 """
 import numpy as np
 import pytest
@@ -15,6 +17,7 @@ from recipe import synth_input, synth_state_dict
 pytestmark = pytest.mark.gpu
 DEV = "cuda"
 BF = torch.bfloat16
+FP32_TOL = 1e-4
 
 
 def q(t):
@@ -93,16 +96,16 @@ def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
         tiles = lib.pk_conv_stats_tiles(B * Ho * Wo)
         part = torch.empty(tiles, 2, Cout, device=DEV)
         call("pk_conv2d_nhwc", xd, wf, out, part, None, B, H, W, Cin, Cout, k, s, 0, Ho, Wo, 0, 1, None, stream_ptr())
-        assert err(nchw(out), ref.detach()) < 2e-3                                   # fp32 output: accumulation order only
+        assert err(nchw(out), ref.detach()) < FP32_TOL                               # fp32 output: accumulation order only
         st = C(part).sum(0)
-        assert err(st[0], ref.detach().sum((0, 2, 3))) < 2e-3
-        assert err(st[1], (ref.detach() ** 2).sum((0, 2, 3))) < 2e-3
+        assert err(st[0], ref.detach().sum((0, 2, 3))) < FP32_TOL
+        assert err(st[1], (ref.detach() ** 2).sum((0, 2, 3))) < FP32_TOL
         raw, _ = N._conv_raw(xd, wf, Cout, k, s, False)
         assert err(nchw(raw), ref.detach()) < 8e-3                                   # bf16 store
         dx = N._conv_dgrad(nhwc(gy), wd, Cin, k, s, (H, W))
         assert err(nchw(dx), xr.grad) < 8e-3
         dw = N._wgrad(xd, nhwc(gy), Cout, Cin, k, s, (B, H, W, Ho, Wo))
-        assert err(C(dw), conv.weight.grad) < 2e-3
+        assert err(C(dw), conv.weight.grad) < FP32_TOL                               # fp32 slabs, fp32 sum: order only
 
 
 def test_stem_conv_padded_input_and_head_out(N):
@@ -134,7 +137,7 @@ def test_stem_conv_padded_input_and_head_out(N):
             yd = nhwc(yq.detach()).requires_grad_(True)
             o = N.head_out(yd, m.h, sp)
             assert o.shape == (2, 17, 8, 6) and o.dtype == torch.float32
-            assert err(C(o), o_ref.detach()) < 2e-3
+            assert err(C(o), o_ref.detach()) < FP32_TOL
             o.backward(go.to(DEV))
             assert err(nchw(yd.grad), yq.grad) < 1e-2                              # dY was rounded to bf16 on the way in
             assert err(C(m.h.weight.grad), head.weight.grad) < 1e-2
@@ -204,7 +207,7 @@ def test_layernorm_fwd_bwd(N, C_):
     assert err(C(y), y_ref.detach()) < 8e-3
     dx, dg, db = N._layernorm_bwd(gy.to(DEV, BF), x.to(DEV, BF), mean, rstd, g.to(DEV), dres.to(DEV, BF))
     assert err(C(dx), xr.grad + dres) < 8e-3
-    assert err(C(dg), gr.grad) < 2e-3 and err(C(db), br.grad) < 2e-3
+    assert err(C(dg), gr.grad) < FP32_TOL and err(C(db), br.grad) < FP32_TOL     # fp32 partials of fp32 x-hat: order only
 
 
 @pytest.mark.parametrize("Cr,Cp", [(78, 80), (156, 160), (312, 320), (624, 640), (640, 640)])
@@ -227,7 +230,7 @@ def test_layernorm_padded_rows(N, Cr, Cp):
     dx, dg, db = N._layernorm_bwd(gy_p.to(DEV, BF), pad(x).to(DEV, BF), mean, rstd, pad(g).to(DEV), pad(dres).to(DEV, BF), c_real=Cr)
     dxc = C(dx)
     assert err(dxc[:, :Cr], xr.grad + dres) < 8e-3 and float(dxc[:, Cr:].abs().max() if Cp > Cr else 0) == 0.0
-    assert err(C(dg)[:Cr], gr.grad) < 2e-3 and err(C(db)[:Cr], br.grad) < 2e-3
+    assert err(C(dg)[:Cr], gr.grad) < FP32_TOL and err(C(db)[:Cr], br.grad) < FP32_TOL
 
 
 def test_linear_rowmaps_gelu_residual(N):
@@ -266,11 +269,11 @@ def test_linear_rowmaps_gelu_residual(N):
     dbias = torch.empty(Cc, device=DEV)
     dw = N._wgrad(tok.to(DEV, BF), gout.to(DEV, BF), Cc, Nn, 1, 1, None, g_map=amap, g_scale=s.to(DEV), g_rps=H * W, M=amap.numel(), dbias=dbias)
     gg = torch.zeros(amap.numel(), Cc)
-    gg[valid] = gout[am[valid]] * s[(am[valid] // (H * W))][:, None]
-    assert err(C(dw), gg.T @ tok) < 1e-2          # scaled rows are re-rounded to bf16 inside the kernel
-    assert err(C(dbias), gg.sum(0)) < 1e-2        # bias gradient from the same staged tile
+    gg[valid] = q(gout[am[valid]] * s[(am[valid] // (H * W))][:, None])      # scaled rows are re-rounded to bf16 inside the kernel
+    assert err(C(dw), gg.T @ tok) < FP32_TOL
+    assert err(C(dbias), gg.sum(0)) < FP32_TOL    # bias gradient from the same staged (rounded) tile
     db = N._colsum(gout.to(DEV, BF), B * H * W, Cc, row_scale=s.to(DEV), rps=H * W)
-    assert err(C(db), (gout * s.repeat_interleave(H * W)[:, None]).sum(0)) < 2e-3
+    assert err(C(db), (gout * s.repeat_interleave(H * W)[:, None]).sum(0)) < FP32_TOL
 
 
 @pytest.mark.parametrize("B,H,W,Nn,Cc,mode", [(2, 9, 10, 32, 32, "gmap"), (3, 16, 12, 64, 64, "gmap"), (2, 16, 12, 128, 128, "gmap"),
@@ -289,7 +292,7 @@ def test_wgrad_window_and_row_scale_streaming(N, B, H, W, Nn, Cc, mode):
     if mode == "gmap":          # proj: G = dy (pixel order) gathered + scaled, X = o (window order)
         g_pix, xw = rnd(M, Nn, seed=1), rnd(Mw, Cc, seed=2)
         gg = torch.zeros(Mw, Nn)
-        gg[valid] = g_pix[am[valid]] * s[am[valid] // (H * W)][:, None]
+        gg[valid] = q(g_pix[am[valid]] * s[am[valid] // (H * W)][:, None])     # the kernel re-rounds the scaled rows to bf16 (MFMA operand)
         kw = dict(g_map=amap, g_scale=s.to(DEV), g_rps=H * W, M=Mw)
         args = (xw.to(DEV, BF), g_pix.to(DEV, BF))
         ref_w, ref_b = gg.T @ xw, gg.sum(0)
@@ -302,16 +305,16 @@ def test_wgrad_window_and_row_scale_streaming(N, B, H, W, Nn, Cc, mode):
         ref_w, ref_b = gw.T @ xg, gw.sum(0)
     else:                       # fc2: G = dy scaled per sample, no maps
         xh, g_pix = rnd(M, Cc, seed=5), rnd(M, Nn, seed=6)
-        gg = g_pix * s.repeat_interleave(H * W)[:, None]
+        gg = q(g_pix * s.repeat_interleave(H * W)[:, None])
         kw = dict(g_scale=s.to(DEV), g_rps=H * W, M=M)
         args = (xh.to(DEV, BF), g_pix.to(DEV, BF))
         ref_w, ref_b = gg.T @ xh, gg.sum(0)
     dw = N._wgrad(*args, Nn, Cc, 1, 1, None, dbias=dbias, win=(B, H, W), **kw)
-    assert err(C(dw), ref_w) < 1e-2 and err(C(dbias), ref_b) < 1e-2
+    assert err(C(dw), ref_w) < FP32_TOL and err(C(dbias), ref_b) < FP32_TOL      # vs the rounding-aware reference: fp32 sums, order only
     if mode != "scale":         # the same launch without the token grid takes the map-loading kernel: same result up to summation order
         db2 = torch.empty(Nn, device=DEV)
         dw2 = N._wgrad(*args, Nn, Cc, 1, 1, None, dbias=db2, **kw)
-        assert err(C(dw), C(dw2)) < 2e-3 and err(C(dbias), C(db2)) < 2e-3
+        assert err(C(dw), C(dw2)) < FP32_TOL and err(C(dbias), C(db2)) < FP32_TOL
 
 
 # ------------------------------------------------------------------------------------------------ attention core

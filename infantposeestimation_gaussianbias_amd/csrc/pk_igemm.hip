@@ -539,12 +539,262 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     }
 }
 
+// ================================================================================================ ring kernel (head convs)
+// The 3x3 256 -> 256 convolutions of the fusion head (forward and data gradient: 8 launches of 232 GFLOP per step, 65 % of the
+// model's flops) on the two-barrier-per-K-step tile above sit at that structure's ceiling (~850 TFLOP/s isolated: every K-step drains
+// the LDS-DMA with vmcnt(0) in front of the barrier).  k_conv8p is the deep-pipeline structure instead:
+//   * 256 pixels x 256 output channels per 512-thread workgroup (8 waves as 2 (pixels) x 4 (channels), 128 x 64 per wave = 128
+//     accumulator registers), one workgroup per CU;
+//   * K-tile = 32 channels of one filter tap = one MFMA k-step: [256 pixel rows | 256 weight rows] x 64 bytes = 32 KB, in a FIVE-stage
+//     LDS ring (160 KB).  Operands travel global -> LDS by LDS-DMA (4 x 1 KiB pieces per wave and tile, XOR swizzle on the source side)
+//     and stay in flight across barriers: tile t+3 is requested while tile t is multiplied, the only vmcnt wait is a counted one
+//     (tile t+1 landed, tiles t+2 and t+3 still in flight: two whole steps of latency cover);
+//   * per K-tile a wave reads 4 weight + 8 pixel fragments (12 ds_read_b128) and issues 32 MFMAs (16x16x32);
+//   * ONE barrier per K-tile.  The two wave groups (waves 0-3 / 4-7: the two waves of every SIMD) run the step in opposite order: between
+//     two barriers group 0 does [reads + DMA issue of tile t; 32 MFMAs of tile t], group 1 [32 MFMAs of tile t-1 from the fragments it
+//     read in the previous interval; reads + DMA issue of tile t] -- while one wave of a SIMD loads, its partner holds the matrix pipe.
+//   (Measured on the way: 64-channel K-tiles in two 64 KB buffers, four quadrant phases of 16 MFMAs and two barriers each, the groups half
+//   a phase apart -- 233 us for the head conv's data gradient against 264 us on k_igemm2; ablations on that version: MFMAs + barriers
+//   alone 157 us (~100 cycles of barrier overhead per 256-cycle MFMA slot), DMA + reads + barriers alone 174 us.  The ring with two
+//   barriers per 32-MFMA step: 211 us.)
+//   (Measured and dropped: PERSISTENT workgroups (one per CU walking its share of the output tiles, the K-tile ring continuing across
+//   tiles, each wave storing its finished tile straight from the accumulators as 16-byte pieces after a v_permlane16_swap while its
+//   partner multiplies) -- 224 / 244 us (data gradient / forward + statistics) against 212 / 229 us for one tile per workgroup with
+//   the LDS-staged 128-byte row stores below; launched with one workgroup per tile the same code ran 224 / 255 us, i.e. the three
+//   lock-step rounds of 256 workgroups cost nothing, the half-line stores do.  Ablations of this version (data gradient, 210 us):
+//   MFMAs + barriers alone 158 us (= the guide's 256 x 256 GEMM rate, i.e. the sustained-clock MFMA ceiling), reads + DMA + barriers
+//   alone 145 us, nothing but prologue / barriers / epilogue 56 us.)
+// Hazards (J_t = interval between barriers t-1 and t; both groups read tile t and request tile t+3 in J_t):
+//   RAW  every wave waits for ITS pieces of tile t+1 (counted vmcnt) before barrier t; the first read of tile t+1 is in J_t+1;
+//   WAR  group 1 fences its reads of tile t-2 (lgkmcnt(0)) at the start of J_t-1, group 0 inside J_t-2; the DMA of tile t+3 into the
+//        same ring stage is issued in J_t.
+// LDS reads of DMA-filled tiles go through inline assembly (see ring_tr above: the compiler would drain the DMA in front of every
+// ds_read it can see).  Supported: stride-1 3x3 / 1x1 convolutions, Cin % 32 == 0 with >= 18 K-tiles, N % 256 == 0, bf16 row-major
+// output, optional BatchNorm statistics; everything else stays on k_igemm2.
+#define C8_STAGE 32768          // bytes per ring stage: [pixels 256 x 64 B | weights 256 x 64 B]
+#define C8_STAGES 5
+template <int OFF>
+__device__ __forceinline__ bf16x8 c8_read(uint32_t lds_byte_addr) {          // OFF: immediate (16-bit) byte offset -- no address VALU per read
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ void c8_fence4(bf16x8& a, bf16x8& b, bf16x8& c, bf16x8& d) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d)::"memory");
+}
+__device__ __forceinline__ void c8_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+__global__ void __launch_bounds__(512, 2) k_conv8p(IgemmArgs p) {
+    __shared__ __attribute__((aligned(1024))) uint16_t c8_smem[C8_STAGES * C8_STAGE / 2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the LDS-DMA destinations (M0) and the group tests are SGPR arithmetic
+    const int grp = wave >> 2;                 // wave group = pixel half of the tile (and the half-step stagger)
+    const int wn = wave & 3;                   // 64-channel quarter
+    // XCD-contiguous tile order (bijective for any grid size): blocks b and b + 8 share an XCD's L2, neighbouring pixel tiles share halo rows
+    int mt, nt;
+    {
+        const int G = gridDim.x, L = blockIdx.x, q = G >> 3, r = G & 7, xcd = L & 7;
+        const int tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (L >> 3);
+        const int ntiles = p.N >> 8;
+        mt = tile / ntiles;
+        nt = tile - mt * ntiles;
+    }
+    const int m0 = mt * 256, n0 = nt * 256;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, 0x7ffffff0, 0x00020000);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)c8_smem;
+
+    // ---- DMA geometry: a 1 KiB piece = 16 rows x 64 bytes; in the pixel tile and in the weight tile this wave moves pieces wave and
+    // 8 + wave, i.e. this thread rows (i * 8 + wave) * 16 + lane / 4, i = 0, 1, physical chunk lane % 4
+    const int drow = wave * 16 + (lane >> 2);
+    const int lchunk = (lane & 3) ^ (((lane >> 5) & 1) << 1);    // logical chunk fetched into physical position lane % 4: ^ swz<32>(row)
+    unsigned pc[2];                                              // byte offset of (pixel, channel lchunk * 8) at the centre tap, or OOB
+    int pedge[2];                                                // bit 0: row above exists, 1: below, 2: left, 3: right
+    unsigned wo[2];                                              // byte offset of weight row n, tap 0, channel lchunk * 8
+    {
+        const int hw = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + i * 128 + drow;
+            pc[i] = OOB_OFF;
+            pedge[i] = 0;
+            if (m < p.M) {
+                const int b = m / hw, rr = m - b * hw, oy = rr / p.Wo, ox = rr - oy * p.Wo;
+                pc[i] = (unsigned)(((b * p.Hs + oy) * p.Ws + ox) * p.Cin + lchunk * 8) * 2u;
+                pedge[i] = (oy > 0 ? 1 : 0) | (oy < p.Hs - 1 ? 2 : 0) | (ox > 0 ? 4 : 0) | (ox < p.Ws - 1 ? 8 : 0);
+            }
+            wo[i] = (unsigned)(((n0 + i * 128 + drow) * p.T) * p.Cin + lchunk * 8) * 2u;
+        }
+    }
+    const int nk = p.T * (p.Cin >> 5);
+    // (tap, first channel) of the tile being requested, with the tap's edge requirements and pixel offset (all wave-uniform)
+    int q_tap = 0, q_c0 = 0, q_need = 0, q_delta = 0;
+    auto set_tap = [&]() {
+        if (p.T == 9) {
+            const int kh = q_tap / 3, kw = q_tap - kh * 3;
+            q_need = (kh == 0 ? 1 : 0) | (kh == 2 ? 2 : 0) | (kw == 0 ? 4 : 0) | (kw == 2 ? 8 : 0);
+            q_delta = ((kh - 1) * p.Ws + (kw - 1)) * p.Cin * 2;
+        }
+    };
+    set_tap();
+    auto issue_tile = [&](int stage) {          // K-tile (q_tap, q_c0) -> ring stage; then advance to the next K-tile
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint16_t* sp = c8_smem + (stage * C8_STAGE + wave * 1024) / 2;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = pc[i] != OOB_OFF && (pedge[i] & q_need) == q_need;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(sp + i * 4096), 16,
+                                                     ok ? pc[i] + (unsigned)q_delta : OOB_OFF, q_c0 * 2, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sp + 8192 + i * 4096), 16, wo[i],
+                                                     (q_tap * p.Cin + q_c0) * 2, 0, 0);
+#endif
+        q_c0 += 32;
+        if (q_c0 >= p.Cin) {
+            q_c0 = 0;
+            ++q_tap;
+            set_tap();
+        }
+    };
+
+    // ---- fragment addresses: row (lane & 15) of a 16-row block, logical chunk lane >> 4, swizzled; blocks are 1024 bytes apart
+    const int frow = lane & 15;
+    const uint32_t fchunk = (uint32_t)(((lane >> 4) ^ ((frow >> 3) << 1)) * 16);
+    const uint32_t faddr_p = lds0 + (grp * 128 + frow) * 64 + fchunk;                        // + stage * 32768 + pixel block * 1024
+    const uint32_t faddr_w = lds0 + 16384 + (wn * 64 + frow) * 64 + fchunk;                  // + stage * 32768 + channel block * 1024
+
+    f32x4 acc[4][8];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // ---- prologue: tiles 0, 1, 2 requested; tile 0 landed
+    issue_tile(0);
+    issue_tile(1);
+    issue_tile(2);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    c8_barrier();
+    int st_r = 0, st_w = 3;                    // ring stage read by this step / filled with tile t + 3
+    bf16x8 wf[4], pf[8];
+    auto multiply = [&]() {
+        c8_fence4(wf[0], wf[1], wf[2], wf[3]);
+        c8_fence4(pf[0], pf[1], pf[2], pf[3]);
+        c8_fence4(pf[4], pf[5], pf[6], pf[7]);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int b = 0; b < 8; ++b)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[a], pf[b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int t = 0; t <= nk; ++t) {
+        if (grp == 1 && t > 0) multiply();                         // group 1: tile t-1, from the fragments it read in the previous interval
+        if (t < nk) {
+            const uint32_t bp = faddr_p + st_r * C8_STAGE, bw = faddr_w + st_r * C8_STAGE;
+            wf[0] = c8_read<0>(bw);
+            wf[1] = c8_read<1024>(bw);
+            wf[2] = c8_read<2048>(bw);
+            wf[3] = c8_read<3072>(bw);
+            pf[0] = c8_read<0>(bp);
+            pf[1] = c8_read<1024>(bp);
+            pf[2] = c8_read<2048>(bp);
+            pf[3] = c8_read<3072>(bp);
+            pf[4] = c8_read<4096>(bp);
+            pf[5] = c8_read<5120>(bp);
+            pf[6] = c8_read<6144>(bp);
+            pf[7] = c8_read<7168>(bp);
+            if (t + 3 < nk) issue_tile(st_w);
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0) multiply();                              // group 0: tile t
+        }
+        // counted wait: tile t+1 has landed (tiles t+2, t+3 may still be in flight)
+        if (t + 3 < nk) {
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else if (t + 2 < nk) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        st_r = st_r == C8_STAGES - 1 ? 0 : st_r + 1;
+        st_w = st_w == C8_STAGES - 1 ? 0 : st_w + 1;
+        c8_barrier();
+    }
+
+    // ---- BatchNorm statistics: a wave's 128 pixels are exactly one statistics tile (STAT_ROWS = 128) of its 64 channels
+    if (p.stats) {
+        float* dst = p.stats + (size_t)(mt * 2 + grp) * 2 * p.N + n0 + wn * 64;
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float sm = 0.f, sq = 0.f;
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const float v = acc[a][b][r];
+                    sm += v;
+                    sq += v * v;
+                }
+                sm = row16_sum(sm);
+                sq = row16_sum(sq);
+                if ((lane & 15) == 0) {
+                    const int nl = a * 16 + (lane >> 4) * 4 + r;
+                    dst[nl] = sm;
+                    dst[p.N + nl] = sq;
+                }
+            }
+    }
+    // ---- epilogue: bf16 tile of the wave (128 pixels x 64 channels = 16 KB) through its own LDS slice, 16-byte chunks XOR-swizzled by
+    // (pixel & 7); then 128-byte row segments to global, 16 bytes per lane
+    uint16_t* stage = c8_smem + wave * 8192;
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const int px = b * 16 + (lane & 15);
+            const int chunk = (a * 2 + (lane >> 5)) ^ (px & 7);
+            uint2 v;
+            v.x = pack_bf16x2(acc[a][b][0], acc[a][b][1]);
+            v.y = pack_bf16x2(acc[a][b][2], acc[a][b][3]);
+            *reinterpret_cast<uint2*>(stage + px * 64 + chunk * 8 + ((lane >> 4) & 1) * 4) = v;
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    uint16_t* out = reinterpret_cast<uint16_t*>(p.out);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int px = it * 8 + (lane >> 3), ch = lane & 7;
+        const int m = m0 + grp * 128 + px;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(stage + px * 64 + ((ch ^ (px & 7)) * 8));
+        if (m < p.M) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n0 + wn * 64 + ch * 8) = v;
+    }
+}
+static inline bool conv8p_takes(const IgemmArgs& a) {
+    // one workgroup per CU: below one full round of 256 tiles the 128 x 128 tiles of k_igemm2 spread the work over more CUs.
+    // (both switches are read per call: the parity tests lower the tile count to run small and ragged shapes through this kernel)
+    const char* on_env = getenv("PK_CONV8P");
+    const char* mt_env = getenv("PK_CONV8P_MIN_TILES");
+    const bool on = !on_env || atoi(on_env) != 0;
+    const long min_tiles = mt_env ? atol(mt_env) : 256;
+    return on && a.Ho > 0 && (a.T == 9 || a.T == 1) && a.stride == 1 && !a.dilated && (a.N % 256) == 0 && (a.Cin % 32) == 0 && a.T * a.Cin >= 576 &&
+           a.out_mode == 0 && !a.bias && !a.res && !a.res_scale && !a.a_rowmap && !a.o_rowmap && !a.preact && !a.gelu_of && a.act == 0 &&
+           a.ldo == a.N && (((uintptr_t)a.out) & 15) == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= min_tiles && a.Hs == a.Ho && a.Ws == a.Wo;
+}
+
 static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) {
     IgemmArgs a = a_in;
     a.vec8 = (a.ldo % 8) == 0 &&
              ((((uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.preact | (uintptr_t)a.gelu_of) & 15) == 0);
     static const int xcd_on = getenv("PK_IGEMM_XCD") ? atoi(getenv("PK_IGEMM_XCD")) : 1;
     a.xcd_remap = xcd_on;
+    if (conv8p_takes(a)) {
+        hipLaunchKernelGGL(k_conv8p, dim3((unsigned)(((a.M + 255) / 256) * (a.N / 256))), dim3(512), 0, st, a);
+        return pk_launch_status(who);
+    }
     const dim3 block(256);
     const unsigned gm = (unsigned)((a.M + 127) / 128);
     // Deep contractions with wide outputs (the 3x3 convs of the head: K = 2304, N = 128/256): 256 x 128 workgroup tile, 128 x 64

@@ -75,7 +75,11 @@ class Holder(torch.nn.Module):
                                                 # 256 -> 256 / 512 at 3x3: the wide weight-gradient kernel (256 x 256 tile, LDS-DMA ring): a
                                                 # slice shorter than one 32-row step, ragged slices, two n-tiles, stride 2
                                                 (1, 5, 4, 256, 256, 3, 1), (3, 23, 17, 256, 256, 3, 1), (2, 12, 10, 256, 512, 3, 1),
-                                                (2, 14, 10, 256, 256, 3, 2), (8, 64, 48, 256, 256, 3, 1)])
+                                                (2, 14, 10, 256, 256, 3, 2), (8, 64, 48, 256, 256, 3, 1),
+                                                # >= 256 pixel tiles of 256 rows with N % 256 == 0, Cin % 64 == 0, K >= 576: the 8-phase kernel
+                                                # k_conv8p (forward, and data gradient where Cout % 64 == 0 and Cin % 256 == 0): ragged last tile,
+                                                # 1 / 2 / 4 channel chunks per tap, two n-tiles, a deep 1x1
+                                                (3, 160, 143, 256, 256, 3, 1), (2, 192, 180, 64, 512, 3, 1), (2, 190, 181, 640, 256, 1, 1)])
 def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
     from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
     conv = torch.nn.Conv2d(Cin, Cout, k, s, k // 2, bias=False)
@@ -106,6 +110,43 @@ def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
         assert err(nchw(dx), xr.grad) < 8e-3
         dw = N._wgrad(xd, nhwc(gy), Cout, Cin, k, s, (B, H, W, Ho, Wo))
         assert err(C(dw), conv.weight.grad) < FP32_TOL                               # fp32 slabs, fp32 sum: order only
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 5, 4, 256, 256), (3, 23, 17, 256, 256), (2, 16, 16, 64, 256), (1, 33, 9, 128, 512), (8, 64, 48, 256, 256)])
+def test_conv8p_small_and_ragged_shapes(N, B, H, W, Cin, Cout, monkeypatch):
+    """k_conv8p (256 x 256 tiles, LDS-DMA half-tiles in flight across barriers, two wave groups half a phase apart) forced onto
+    shapes of a few tiles: a tile with 20 live rows, ragged tails, images narrower than a tile row (every tap crosses image rows and
+    samples inside one tile), 1 / 2 / 4 channel chunks per tap, two n-tiles; forward with the BatchNorm statistics and the data
+    gradient, against fp32 PyTorch and against k_igemm2 on the same operands, bit-identical run to run."""
+    monkeypatch.setenv("PK_CONV8P_MIN_TILES", "1")
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight * 3))
+    x = rnd(B, Cin, H, W, seed=11)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(xr, conv.weight, None, 1, 1)
+    gy = rnd(*ref.shape, seed=12)
+    ref.backward(gy)
+    import copy
+    m = Holder(c=copy.deepcopy(conv)).to(DEV)
+    with N.use_weights(m) as wc:
+        wf, wd = wc.fwd[id(m.c.weight)], wc.dgrad[id(m.c.weight)]
+        xd = nhwc(x)
+        raw, part = N._conv_raw(xd, wf, Cout, 3, 1, True)
+        assert err(nchw(raw), ref.detach()) < 8e-3                                   # bf16 store
+        st = C(part).sum(0)
+        assert err(st[0], ref.detach().sum((0, 2, 3))) < FP32_TOL                    # statistics come from the fp32 accumulators
+        assert err(st[1], (ref.detach() ** 2).sum((0, 2, 3))) < FP32_TOL
+        raw2, part2 = N._conv_raw(xd, wf, Cout, 3, 1, True)
+        assert torch.equal(raw, raw2) and torch.equal(part, part2)
+        dx = N._conv_dgrad(nhwc(gy), wd, Cin, 3, 1, (H, W)) if (Cout % 64 == 0 and Cin % 256 == 0) else None
+        monkeypatch.setenv("PK_CONV8P", "0")                                         # the same launches on k_igemm2
+        raw3, _ = N._conv_raw(xd, wf, Cout, 3, 1, True)
+        assert err(C(raw), C(raw3)) < 8e-3 and float((C(raw) != C(raw3)).float().mean()) < 0.02      # same fp32 sums up to order: rare 1-ulp flips
+        if dx is not None:
+            assert err(nchw(dx), xr.grad) < 8e-3
+            dx3 = N._conv_dgrad(nhwc(gy), wd, Cin, 3, 1, (H, W))
+            assert err(C(dx), C(dx3)) < 8e-3
 
 
 def test_stem_conv_padded_input_and_head_out(N):

@@ -38,7 +38,9 @@ CONFIGS = {
     "hrformer_small": dict(preset="hrformer_small", batch=64, mode="train", metric="images/sec (train fwd+bwd) HRFormer-S 256x192",
                            workload="HRFormer-small + fusion head, 256x192 -> 64x48, K=17, train step fwd+bwd+AdamW, DropPath 0.1, BN train"),
     "hrnet_w32_384": dict(preset="hrnet_w32", batch=32, mode="train", metric="images/sec (train fwd+bwd) HRNet-W32 384x288",
-                          workload="HRNet-W32 + heatmap head (KeypointMSELoss), 384x288 -> 96x72, K=17, train step fwd+bwd+AdamW, BN train"),
+                          workload="HRNet-W32 + heatmap head (KeypointMSELoss), 384x288 -> 96x72, K=17, train step fwd+bwd+AdamW, BN train; "
+                                   "per-GPU batch 32 = the reference's TrainConfig.batch_size default (configs/config.py; its configs/hrnet_w32.yaml is an empty file "
+                                   "and BASELINE.json states no batch for this config)"),
     "hrformer_base_infer": dict(preset="preemie", batch=32, mode="infer", metric="images/sec (flip-test inference) HRFormer-B 384x288",
                                 workload="HRFormer-base + fusion head, K=13, 384x288 -> 96x72, flip-test inference (2 forwards + flip merge + decode), "
                                          "8-aligned padded twin"),
@@ -79,26 +81,72 @@ def time_kernel(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-def _entry(kernel, what, bound, sec, flops=None, bytes_=None, traffic=None, launches=None):
-    if bound == "mfma":
-        ach, peak, unit = flops / sec / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
-    else:
-        ach, peak, unit = bytes_ / sec / 1e9, HBM_PEAK_GBS, "GB/s"
+PROFILE_CSV = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")      # rocprofv3 --kernel-trace --stats of `python bench.py --steps 4 --warmup 2`
+
+
+def load_step_profile():
+    """Per-kernel in-step numbers from the committed rocprof summary of THIS command: {kernel name: (launches per step, average us)}.
+    Steps in the trace = launches of k_adamw (one per step, eager warm-up steps and graph replays alike)."""
+    import csv
+    try:
+        with open(PROFILE_CSV) as f:
+            rows = list(csv.DictReader(f))
+    except OSError:
+        return {}, 0
+    steps = max([int(r["Calls"]) for r in rows if r["Name"].startswith("k_adamw")] or [0])
+    if not steps:
+        return {}, 0
+    return {r["Name"].replace("void ", ""): (int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3) for r in rows}, steps
+
+
+def load_pmc():
+    """-> (isolated, step): L2-miss bytes per launch from the --pmc passes over scripts/prof_kernels.py.  `isolated` has one shape per kernel
+    name (the roofline probes' shapes); `step` is the mean over every launch of that name in an eager step: exact only for single-shape kernels."""
+    out = []
+    for name in ("r03_pmc_traffic_isolated.json", "r03_pmc_traffic_step.json"):
+        try:
+            with open(os.path.join(ROOT, "profiles", name)) as f:
+                out.append(json.load(f)["kernels"])
+        except (OSError, KeyError, ValueError):
+            out.append({})
+    return out
+
+
+def _entry(kernel, what, bound, sec, flops=None, bytes_=None, trace=None, single_shape=False, prof=None, pmc=None):
+    """One roofline row.  `sec`: the probe's average launch duration measured live (isolated, contention-free).  `trace`: the kernel's
+    name in the rocprof summary; `us_in_step_avg` / `launches_per_step` come from profiles/ (same command, whole step, concurrent
+    streams), and `frac_in_step` is the same algorithmic work over that in-step average -- only where every launch of that kernel name
+    in the step has the probe's shape (`single_shape`); template kernels that serve many shapes get null."""
+    work = flops if bound == "mfma" else bytes_
+    peak, unit, scale = (MFMA_BF16_PEAK_TFLOPS, "TFLOP/s", 1e12) if bound == "mfma" else (HBM_PEAK_GBS, "GB/s", 1e9)
+    ach = work / sec / scale
     e = {"kernel": kernel, "shape": what, "bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4),
-         "traffic": traffic, "us_per_launch": round(sec * 1e6, 1)}
+         "us_per_launch": round(sec * 1e6, 1), "traffic": None}
     if flops:
         e["algorithmic_flops"] = flops
     if bytes_:
         e["algorithmic_bytes"] = bytes_
-    if launches:
-        e["launches_per_step"] = launches
+    if pmc and trace:
+        key = trace.split("(")[0]
+        iso, stp = pmc
+        if key in iso:
+            e["traffic"] = iso[key]["traffic_bytes"]
+        elif single_shape and key in stp:
+            e["traffic"] = stp[key]["traffic_bytes"]
+    if prof and trace and trace in prof:
+        lps, us = prof[trace]
+        e["launches_per_step"] = round(lps, 2)
+        e["us_in_step_avg"] = round(us, 1)
+        e["ms_in_step"] = round(lps * us / 1e3, 3)
+        e["frac_in_step"] = round(work / (us * 1e-6) / scale / peak, 4) if single_shape else None
     return e
 
 
-def roofline_table(model, B):
-    """The top aggregate kernels of the step (profiles/r02_trace_summary.txt), each on its dominant shape, timed live here.
-    Algorithmic work: GEMM-shaped kernels 2*M*N*K flops vs the dense bf16 MFMA peak; the shallow token GEMMs and the
-    fused block kernels are HBM-bound: bytes = every operand read once + every result written once."""
+def roofline_table(model, B, trainer=None):
+    """The kernels that top the aggregate of the step (profiles/r03_trace_summary.txt), each on its dominant shape, timed live here and
+    set beside its in-step numbers from profiles/.  Algorithmic work: GEMM-shaped kernels 2*M*N*K flops vs the dense
+    bf16 MFMA peak; the shallow token GEMMs, the fused block kernels, BatchNorm and the slab reduction are HBM-bound: bytes = every
+    operand read once + every result written once."""
     from infantposeestimation_gaussianbias_amd import _lib, nnops
     from infantposeestimation_gaussianbias_amd._lib import call, stream_ptr
     dev = next(model.parameters()).device
@@ -106,17 +154,12 @@ def roofline_table(model, B):
     H, W = 64, 48
     M = B * H * W
     out = []
-    traffic = traffic_w3 = None
-    try:
-        # PMC passes are offline (two rocprofv3 --pmc runs, scripts/pmc_summary.py); regenerated whenever one of the kernels changes
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_head_conv_traffic.json")) as f:
-            pm = json.load(f)["kernels"]
-        traffic = pm["k_igemm2<256, 128, 2, 2, 32>"]["traffic_bytes"]      # mean over the forward and data-gradient launches
-        traffic_w3 = pm["k_wgrad3"]["traffic_bytes"]
-    except (OSError, KeyError, ValueError):
-        pass
+    prof, steps_in_trace = load_step_profile()
+    pmc = load_pmc()
+    E = lambda *a, **k: out.append(_entry(*a, prof=prof, pmc=pmc, **k))
     with nnops.use_weights(model) as wc:
-        # 1. head conv 3x3 256->256 @64x48 (fusion_head.py:215,224,235), forward with the BN-statistics epilogue: 12 launches per step (fwd + dgrad)
+        # 1. head conv 3x3 256->256 @64x48 (fusion_head.py:215,224,235), forward with the BN-statistics epilogue; the same kernel runs the
+        #    data gradient: 8 launches of this shape per step
         conv = model.head.shared_layers["3"]
         C = conv.weight.shape[1]
         x = torch.randn(B, H, W, C, device=dev).to(BF)
@@ -124,8 +167,8 @@ def roofline_table(model, B):
         wf = wc.fwd[id(conv.weight)]
         flops = 2.0 * M * conv.weight.shape[0] * 9 * C
         sec = time_kernel(lambda: nnops._conv_raw(x, wf, conv.weight.shape[0], 3, 1, True))
-        out.append(_entry("k_igemm2<256,128,2,2,32>", "head conv3x3 256->256 @64x48, fwd + BN-stat epilogue", "mfma", sec, flops=flops,
-                          bytes_=2.0 * (2 * M * C) + 2 * 9 * C * C, traffic=traffic, launches=8))
+        E("k_conv8p", "head conv3x3 256->256 @64x48, fwd + BN-stat epilogue (same kernel: data gradient)", "mfma", sec, flops=flops,
+          bytes_=2.0 * (2 * M * C) + 2 * 9 * C * C, trace="k_conv8p(IgemmArgs)", single_shape=True)
         # Weight gradients as the step launches them: slabs only (dw = NULL), the split-M partial sums of ALL layers are reduced by
         # the step's one k_reduce_many launch.
         def wgrad_slabs(xx, gg, Mr, N_, Cin_, ks, geom, a_map=None):
@@ -136,30 +179,35 @@ def roofline_table(model, B):
             ws = torch.empty(S * N_ * (ks * ks * Cin_ + 1), device=dev)
             return lambda: call("pk_wgrad_bf16", xx, gg, ws, None, None, 0, a_map, None, None, 0, Mr, N_, Cin_, ks, 1, Bq, Hq, Wq, Ho, Wo, 0,
                                 stream_ptr())
-        # 2. the head conv's weight gradient: k_wgrad3 (256 x 256 tile, 4-stage LDS-DMA ring), 3 launches per step
+        # 2. the head conv's weight gradient: k_wgrad3 (256 x 256 tile, 5-stage LDS-DMA ring)
         sec = time_kernel(wgrad_slabs(x, g, M, C, C, 3, (B, H, W)))
-        out.append(_entry("k_wgrad3", "head conv3x3 256->256 @64x48 weight gradient (slabs)", "mfma", sec, flops=flops,
-                          bytes_=2.0 * (2 * M * C), traffic=traffic_w3, launches=3))
+        E("k_wgrad3", "head conv3x3 256->256 @64x48 weight gradient (slabs)", "mfma", sec, flops=flops, bytes_=2.0 * (2 * M * C),
+          trace="k_wgrad3(WgradArgs)", single_shape=True)
         # 3. streaming weight gradient k_wgrad4<128,64>: qkv weight gradient of the branch-0 blocks (tokens x 96 x 32)
         Mw = B * 70 * 49
         u, dq = torch.randn(Mw, 32, device=dev).to(BF), torch.randn(Mw, 96, device=dev).to(BF)
         sec = time_kernel(wgrad_slabs(u, dq, Mw, 96, 32, 1, None))
-        out.append(_entry("k_wgrad4<128,64>", "qkv weight gradient, branch 0: 219520 tokens x 96 x 32 (slabs)", "hbm", sec,
-                          flops=2.0 * Mw * 96 * 32, bytes_=2.0 * Mw * (96 + 32), launches=14))
-        # 3b. k_wgrad4w<128,64> (windowed / row-scaled streaming kernel, 104 launches over its four tile variants): qkv weight gradient of
-        # the branch-1 blocks, x gathered through the 7x7 window partition (recomputed per DMA lane)
+        E("k_wgrad4<128,64>", "qkv weight gradient, branch 0: 219520 tokens x 96 x 32 (slabs)", "hbm", sec, flops=2.0 * Mw * 96 * 32,
+          bytes_=2.0 * Mw * (96 + 32), trace="k_wgrad4<128, 64, false>(WgradArgs)")
+        # 3b. k_wgrad4w<128,64> (windowed / row-scaled streaming kernel): qkv weight gradient of the branch-1 blocks, x gathered through
+        # the 7x7 window partition (recomputed per DMA lane)
         amap1, nwin1 = nnops.window_rowmap(B, 32, 24, dev)
         Mw1 = amap1.numel()
         u1, dq1 = torch.randn(B * 32 * 24, 64, device=dev).to(BF), torch.randn(Mw1, 192, device=dev).to(BF)
         sec = time_kernel(wgrad_slabs(u1, dq1, Mw1, 192, 64, 1, (B, 32, 24), a_map=amap1))
-        out.append(_entry("k_wgrad4w<128,64>", f"qkv weight gradient, branch 1: {Mw1} window tokens x 192 x 64, gathered rows (slabs)", "hbm",
-                          sec, flops=2.0 * Mw1 * 192 * 64, bytes_=2.0 * (Mw1 * 192 + B * 32 * 24 * 64), launches=14))
-        # 4. k_igemm2<128,64,4,1,64>: dominant shape = 3x3 conv 64->64 @64x48 (layer1 / transition convs), forward with BN statistics
+        E("k_wgrad4w<128,64>", f"qkv weight gradient, branch 1: {Mw1} window tokens x 192 x 64, gathered rows (slabs)", "hbm", sec,
+          flops=2.0 * Mw1 * 192 * 64, bytes_=2.0 * (Mw1 * 192 + B * 32 * 24 * 64), trace="k_wgrad4w<128, 64>(WgradArgs)")
+        # 4. k_igemm2<128,64,4,1,64>: its largest shape = 3x3 conv 64->64 @64x48 (layer1 / transition convs), forward with BN statistics
         x64 = torch.randn(B, H, W, 64, device=dev).to(BF)
         w64 = torch.randn(64, 9, 64, device=dev).to(BF)
         sec = time_kernel(lambda: nnops._conv_raw(x64, w64, 64, 3, 1, True))
-        out.append(_entry("k_igemm2<128,64,4,1,64>", "conv3x3 64->64 @64x48 fwd + BN-stat epilogue", "mfma", sec, flops=2.0 * M * 64 * 9 * 64,
-                          bytes_=2.0 * (2 * M * 64), launches=76))
+        E("k_igemm2<128,64,4,1,64>", "conv3x3 64->64 @64x48 fwd + BN-stat epilogue", "mfma", sec, flops=2.0 * M * 64 * 9 * 64,
+          bytes_=2.0 * (2 * M * 64), trace="k_igemm2<128, 64, 4, 1, 64>(IgemmArgs)")
+        # 4b. k_igemm2<128,32,4,1,64>: largest shape = 3x3 conv 256->32 @64x48 (transition1 branch 0 forward / data gradient of the head's 32->256 conv)
+        w32 = torch.randn(32, 9, 256, device=dev).to(BF)
+        sec = time_kernel(lambda: nnops._conv_raw(x, w32, 32, 3, 1, True))
+        E("k_igemm2<128,32,4,1,64>", "conv3x3 256->32 @64x48 fwd + BN-stat epilogue", "mfma", sec, flops=2.0 * M * 32 * 9 * 256,
+          bytes_=2.0 * (M * 256 + M * 32), trace="k_igemm2<128, 32, 4, 1, 64>(IgemmArgs)")
         # 5./6. the fused block halves of branch 0 (C = 32): bytes = x in + y out (forward), x + dy in, dx out (backward)
         blk = model.backbone.stage2[0].branches[0][0]
         xb = torch.randn(B, H, W, 32, device=dev).to(BF)
@@ -170,8 +218,8 @@ def roofline_table(model, B):
             with torch.no_grad():
                 sec = time_kernel(lambda: nnops._MlpHalfFused.apply(xb, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight,
                                                                     m.fc2.bias, s))
-            out.append(_entry("k_mlp_fwd<32>", "LN2+fc1+GELU+fc2+residual, 196608 tokens x 32 (hidden 128 in registers)", "hbm", sec,
-                              flops=16.0 * M * 32 * 32, bytes_=4.0 * M * 32, launches=14))
+            E("k_mlp_fwd<32>", "LN2+fc1+GELU+fc2+residual, 196608 tokens x 32 (hidden 128 in registers)", "hbm", sec,
+              flops=16.0 * M * 32 * 32, bytes_=4.0 * M * 32, trace="k_mlp_fwd<32>(MlpArgs)", single_shape=True)
         if nnops.fused_attn_enabled(32, 1):
             aargs = (blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias, a.proj.weight, a.proj.bias, s, 1)
             y, o, lse, amap = nnops.attn_half_fused_forward(xb, *aargs, save=True)
@@ -182,23 +230,90 @@ def roofline_table(model, B):
             sec = time_kernel(lambda: call("pk_attn_block_bwd", gy, xb, amap, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table,
                                            wc.fwd[id(a.qkv.weight)], a.qkv.bias, wc.dgrad[id(a.qkv.weight)], wc.dgrad[id(a.proj.weight)], s, o, lse,
                                            dx, dqkv, u_w, lnp, rpb, nw, nw // B, 1, 32, 1e-5, stream_ptr()))
-            out.append(_entry("k_attn_bwd<32>", "attention-half backward, 4480 windows x 49 tokens x 32 (dx + dqkv + u)", "hbm", sec,
-                              bytes_=2.0 * (3 * M * 32 + nw * 49 * (32 + 96 + 32)), launches=14))
+            E("k_attn_bwd<32>", "attention-half backward, 4480 windows x 49 tokens x 32 (dx + dqkv + u)", "hbm", sec,
+              bytes_=2.0 * (3 * M * 32 + nw * 49 * (32 + 96 + 32)), trace="k_attn_bwd<32>(AttnArgs, float*, float*)", single_shape=True)
+    # 7. BatchNorm on the head-sized tensors (196608 x 256: 100 MB each): apply (raw -> y), backward reduce (dy, y, raw read), backward apply
+    C2 = 256
+    raw, y, dy = (torch.randn(M, C2, device=dev).to(BF) for _ in range(3))
+    vec = lambda: torch.rand(C2, device=dev) + 0.5
+    scale, shift, mean, rstd, gamma = vec(), vec(), vec(), vec(), vec()
+    yo = torch.empty_like(raw)
+    sec = time_kernel(lambda: call("pk_bn_act", raw, scale, shift, None, yo, M, C2, 1, stream_ptr()))
+    E("k_bn_act", "scale/shift + ReLU, 196608 x 256 (raw in, y out)", "hbm", sec, bytes_=4.0 * M * C2, trace=next((k for k in prof if k.startswith("k_bn_act(")), None))
+    nbb = _lib.lib.pk_bn_bwd_blocks(M)
+    part, sums, dga, dbe = torch.empty(nbb, 2, C2, device=dev), torch.empty(2 * C2, device=dev), torch.empty(C2, device=dev), torch.empty(C2, device=dev)
+    draw = torch.empty_like(raw)
+    sec = time_kernel(lambda: call("pk_bn_bwd", dy, y, raw, mean, rstd, gamma, part, sums, dga, dbe, draw, None, M, C2, 1, stream_ptr()))
+    E("k_bn_bwd_reduce + k_sum_partials + k_bn_bwd_apply", "BatchNorm backward, 196608 x 256: two passes over (dy, y, raw) + dx out (three launches)", "hbm",
+      sec, bytes_=2.0 * M * C2 * (3 + 3 + 1), trace=None)
+    # 8. the step's slab reduction (ONE launch for all layers): bytes = every slab read once + every gradient written once
+    tabs = [(k, t) for k, t in nnops._TABLES.items()]
+    if tabs:
+        key, tab = max(tabs, key=lambda kt: sum(r[3] * r[4] for r in kt[0]))
+        slab_bytes = 4.0 * sum(r[3] * r[4] + r[4] for r in key)
+        sec = time_kernel(lambda: call("pk_reduce_many", tab["desc"], tab["blk_desc"], tab["blk_first"], tab["nb"], stream_ptr()), iters=5)
+        E("k_reduce_many", f"slab reduction of the whole step: {len(key)} rows, {tab['nb']} workgroups", "hbm", sec, bytes_=slab_bytes,
+          trace="k_reduce_many(ReduceDesc const*, int const*, int const*)")       # (the trace also holds the first warm-up step's per-layer reductions)
+    # 9. input pipeline (f2; not part of the synthetic step): inverse-affine crop + normalise of 64 640x480 uint8 images -> bf16 NHWC-8
+    try:
+        import numpy as np
+        from infantposeestimation_gaussianbias_amd.datasets import transforms as T
+        imgs = [np.random.default_rng(i).integers(0, 255, (480, 640, 3), dtype=np.uint8) for i in range(4)] * (B // 4)
+        mats = [np.array([[0.4, 0.0, -32.0], [0.0, 0.4, 32.0]], np.float64)] * len(imgs)
+        crop = T.DeviceCropper((192, 256), dev, nchw=False, nhwc8=True)
+        t0 = time.perf_counter()
+        for _ in range(3):
+            crop(imgs, mats)
+        torch.cuda.synchronize()
+        sec = (time.perf_counter() - t0) / 3
+        E("k_affine_crop_normalize (+ host staging)", "64 x 640x480x3 uint8 -> 64 x 256x192 bf16 NHWC-8: wall time incl. the pinned-host copy (PCIe)", "hbm",
+          sec, bytes_=float(len(imgs) * (480 * 640 * 3 + 256 * 192 * 16)), trace=None)
+    except Exception as e:       # noqa: BLE001  (the probe is informational)
+        log(f"input-pipeline probe skipped: {type(e).__name__}: {e}")
+    for e in out:
+        e["steps_in_trace"] = steps_in_trace
     return out
 
 
-def cpu_baseline(cfg_name, c):
-    """CPU oracle train step (B=8: ~2 s/step on 16 cores -> 2 warm-up + 5 timed steps)."""
+def cpu_baseline(cfg_name, c, cfg):
+    """The CPU oracle (parity-pinned port of the reference, fp32 PyTorch-CPU) on this host's cores: a bounded sample of the same workload."""
     from oracle import train_step as ots
     with open(os.path.join(ROOT, "tests", "golden", "state_keys.json")) as f:
         keys = json.load(f)
     cores = max(1, min(len(os.sched_getaffinity(0)), 16))      # the GPU box gives one job a 16-CPU share of a much larger host
-    if cfg_name != "hrformer_small":
-        return None
-    ips, threads = ots.time_train_steps(keys["hrformer_small_fusion"], keys["hrformer_small_fusion#params"], B=8, steps=5, warmup=2,
-                                        input_size=c["input"], heatmap_size=c["heatmap"], K=c["K"], threads=cores)
-    return {"value": round(ips, 3), "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "HRFormer-small fusion 256x192 train step (fwd+bwd+AdamW), fp32 PyTorch-CPU oracle, B=8, 2 warm-up + 5 timed steps"}
+    if cfg_name == "hrformer_small":
+        ips, threads = ots.time_train_steps(keys["hrformer_small_fusion"], keys["hrformer_small_fusion#params"], B=8, steps=5, warmup=2,
+                                            input_size=c["input"], heatmap_size=c["heatmap"], K=c["K"], threads=cores)
+        sample = "HRFormer-small fusion 256x192 train step (fwd+bwd+AdamW), fp32 PyTorch-CPU oracle, B=8, 2 warm-up + 5 timed steps"
+    elif cfg_name == "hrnet_w32_384":
+        ips, threads = ots.time_train_steps(keys["hrnet_w32_heatmap"], keys["hrnet_w32_heatmap#params"], B=4, steps=3, warmup=1,
+                                            input_size=c["input"], heatmap_size=c["heatmap"], K=c["K"], threads=cores)
+        sample = "HRNet-W32 heatmap head 384x288 train step (fwd+bwd+AdamW), fp32 PyTorch-CPU oracle, B=4, 1 warm-up + 3 timed steps"
+    else:
+        pairs = cfg.data.flip_pairs or [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12)]
+        ips, threads = ots.time_flip_inference(keys["hrformer_base_fusion_k13"], pairs, B=4, steps=3, warmup=1, input_size=c["input"], threads=cores)
+        sample = "HRFormer-base fusion K=13 384x288 flip-test inference, fp32 PyTorch-CPU oracle, B=4, 1 warm-up + 3 timed passes"
+    return {"value": round(ips, 3), "unit": "images/sec", "cores": threads, "kind": "port", "sample": sample}
+
+
+def roofline_other(cfg_name, model, B, c):
+    """--config hrnet_w32_384 / hrformer_base_infer: the dominant hand-written kernel of that configuration, timed live on its dominant shape."""
+    from infantposeestimation_gaussianbias_amd import nnops
+    dev = next(model.parameters()).device
+    BF = torch.bfloat16
+    if cfg_name == "hrnet_w32_384":
+        # branch 0 BasicBlock conv3x3 32->32 @96x72 (hrnet.py:24-52): 16 blocks x 2 convs forward + as many data gradients
+        H, W, C = 96, 72, 32
+        x, w = torch.randn(B, H, W, C, device=dev).to(BF), torch.randn(C, 9, C, device=dev).to(BF)
+        sec = time_kernel(lambda: nnops._conv_raw(x, w, C, 3, 1, True))
+        return [_entry("k_igemm2<128,32,4,1,32>", f"BasicBlock conv3x3 32->32 @96x72, B={B}, fwd + BN-stat epilogue", "hbm", sec,
+                       flops=2.0 * B * H * W * C * 9 * C, bytes_=2.0 * 2 * B * H * W * C)]
+    # HRFormer-base twin: head conv 3x3 256->256 @96x72 (the head dominates: 2 x 4 launches per flip-test pass)
+    H, W, C = 96, 72, 256
+    x, w = torch.randn(B, H, W, C, device=dev).to(BF), torch.randn(C, 9, C, device=dev).to(BF)
+    sec = time_kernel(lambda: nnops._conv_raw(x, w, C, 3, 1, False))
+    return [_entry("k_conv8p", f"head conv3x3 256->256 @96x72, B={B}, forward (eval: no statistics)", "mfma", sec, flops=2.0 * B * H * W * C * 9 * C,
+                   bytes_=2.0 * 2 * B * H * W * C)]
 
 
 class InferRunner:
@@ -295,7 +410,7 @@ def main():
     if not streams:
         os.environ["POSE_STREAMS"] = "0"
     batch = synthetic_batch(B, c["input"], c["heatmap"], c["K"], cfg.data.sigma, dev, seed=1234 + rank)
-    calls_per_step, launch = None, None
+    calls_per_step, launch, trainer = None, None, None
 
     if c["mode"] == "train":
         # default: the whole step (zero_grad + fwd + bwd + gradient exchange + AdamW) is one hipGraph whose branches fork/join across HIP streams
@@ -362,15 +477,16 @@ def main():
     if rank == 0:
         log(f"timed region: {dt:.3f} s for {args.steps} steps -> {B * world * args.steps / dt:.1f} img/s")
         roof = None
-        if args.config == "hrformer_small" and not args.no_roofline:
-            table = roofline_table(model, B)
+        if not args.no_roofline:
+            table = roofline_table(model, B, trainer) if args.config == "hrformer_small" else roofline_other(args.config, model, B, c)
             roof = dict(table[0])
             roof["table"] = table
             for e in table:
-                log(f"roofline: {e['kernel']:40s} {e['us_per_launch']:8.1f} us  {e['achieved']:8.1f} {e['unit']} = {e['frac'] * 100:5.1f} % of {e['bound']} peak")
+                log(f"roofline: {e['kernel'][:48]:48s} {e['us_per_launch']:8.1f} us isolated ({e.get('us_in_step_avg', '-')} in step)  "
+                    f"{e['achieved']:8.1f} {e['unit']} = {e['frac'] * 100:5.1f} % of {e['bound']} peak")
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
-            cpu = cpu_baseline(args.config, c)
+            cpu = cpu_baseline(args.config, c, cfg)
             log(f"cpu baseline: {cpu}")
         line = {
             "metric": c["metric"], "value": round(B * world * args.steps / dt, 2),

@@ -1112,7 +1112,7 @@ __device__ __forceinline__ bf16x8 ring_join(const s16x4& lo, const s16x4& hi) {
     return (bf16x8){lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
 }
 #define W3_ROWS 32
-#define W3_STAGES 4
+#define W3_STAGES 5
 __device__ __forceinline__ int w3_swz(int row) { return 2 * (row & 3) + 8 * ((row >> 3) & 1); }
 __device__ __forceinline__ void w3_frag(const uint16_t* tile, int col0, int lane, s16x4& lo, s16x4& hi) {
     const int g = lane >> 4, i = lane & 15, q = i >> 2, pq = i & 3;
@@ -1163,8 +1163,8 @@ __global__ void __launch_bounds__(512, 2) k_wgrad3(WgradArgs p) {
     int issued = 0;
     auto issue_next = [&]() {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const int st = issued & (W3_STAGES - 1);
-        ++issued;
+        const int st = issued;
+        issued = issued == W3_STAGES - 1 ? 0 : issued + 1;
         uint16_t* sg = w3_smem + st * 2 * TILE;
         uint16_t* sx = sg + TILE;
 #pragma unroll
@@ -1197,39 +1197,51 @@ __global__ void __launch_bounds__(512, 2) k_wgrad3(WgradArgs p) {
     issue_next();
     issue_next();
     issue_next();
-    for (int s = 0; s < nsteps; ++s) {
-        // step s's four pieces of this wave have landed when at most the 8 younger ones are outstanding; the barrier then covers the
-        // other waves' pieces and guarantees everyone has finished reading stage (s - 1) & 3, which the next issue overwrites
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        issue_next();
-        const uint16_t* sg = w3_smem + (s & (W3_STAGES - 1)) * 2 * TILE;
-        const uint16_t* sx = sg + TILE;
-        s16x4 gl[4], gh[4], xl[8], xh[8];
-#pragma unroll
-        for (int a = 0; a < 4; ++a) w3_frag(sg, wn * 64 + a * 16, lane, gl[a], gh[a]);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) w3_frag(sx, wc * 128 + b * 16, lane, xl[b], xh[b]);
+    // ONE barrier per step, the two waves of every SIMD (wave groups 0-3 / 4-7) in opposite order between two barriers (k_conv8p has the
+    // hazard analysis): group 0 [reads + DMA issue of step s; 32 MFMAs of step s], group 1 [32 MFMAs of step s-1 from the fragments it
+    // read in the previous interval; reads + DMA issue of step s].  Step s+3 goes into the stage of step s-2, whose reads group 1 fenced
+    // at the start of the previous interval: FIVE stages.  The counted wait (this wave's pieces of step s+1 landed, s+2 and s+3 may be
+    // in flight) sits in front of the barrier that lets anyone read step s+1.  (Before: every wave read, then every wave multiplied,
+    // behind one barrier per step -- the matrix pipe idled during each read phase: 300 us for the head conv.)
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    s16x4 gl[4], gh[4], xl[8], xh[8];
+    auto multiply = [&]() {
         ring_fence(gl[0], gh[0], gl[1], gh[1], gl[2], gh[2], gl[3], gh[3]);
         ring_fence(xl[0], xh[0], xl[1], xh[1], xl[2], xh[2], xl[3], xh[3]);
-#pragma unroll
-        for (int b = 4; b < 8; ++b) w3_frag(sx, wc * 128 + b * 16, lane, xl[b], xh[b]);      // in flight under the first 16 MFMAs
+        ring_fence(xl[4], xh[4], xl[5], xh[5], xl[6], xh[6], xl[7], xh[7]);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
         bf16x8 gf[4];
 #pragma unroll
         for (int a = 0; a < 4; ++a) gf[a] = ring_join(gl[a], gh[a]);
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
+        for (int b = 0; b < 8; ++b) {
             const bf16x8 xf = ring_join(xl[b], xh[b]);
 #pragma unroll
             for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf, acc[a][b], 0, 0, 0);
         }
-        ring_fence(xl[4], xh[4], xl[5], xh[5], xl[6], xh[6], xl[7], xh[7]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int st_r = 0;
+    for (int s = 0; s <= nsteps; ++s) {
+        if (grp == 1 && s > 0) multiply();                          // group 1: step s-1
+        if (s < nsteps) {
+            const uint16_t* sg = w3_smem + st_r * 2 * TILE;
+            const uint16_t* sx = sg + TILE;
 #pragma unroll
-        for (int b = 4; b < 8; ++b) {
-            const bf16x8 xf = ring_join(xl[b], xh[b]);
+            for (int a = 0; a < 4; ++a) w3_frag(sg, wn * 64 + a * 16, lane, gl[a], gh[a]);
 #pragma unroll
-            for (int a = 0; a < 4; ++a) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(gf[a], xf, acc[a][b], 0, 0, 0);
+            for (int b = 0; b < 8; ++b) w3_frag(sx, wc * 128 + b * 16, lane, xl[b], xh[b]);
+            issue_next();                                           // step s+3 (zero tiles beyond the slice)
+            __builtin_amdgcn_sched_barrier(0);
+            if (grp == 0) multiply();                               // group 0: step s
         }
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        st_r = st_r == W3_STAGES - 1 ? 0 : st_r + 1;
+        __builtin_amdgcn_s_barrier();
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the run-ahead zero tiles must have landed before the LDS is released
     float* dst = p.part + (size_t)zslice * p.N * p.T * p.Cin;

@@ -87,3 +87,33 @@ def time_train_steps(spec, pnames, B=8, steps=3, warmup=1, input_size=(192, 256)
         train_step(P, pnames, state, warmup + s + 1, batch, input_size)
     dt = time.perf_counter() - t0
     return B * steps / dt, torch.get_num_threads()
+
+
+def flip_inference(P, img, flip_pairs):
+    """PoseEstimator.inference with flip test (pose_estimator.py:275-329): two eval forwards, the flipped pass's heatmaps flipped
+    back with left/right channels swapped and averaged, offsets of the un-flipped pass, head.decode (fusion_head.py:309-365)."""
+    from . import decode as odec
+    with torch.no_grad():
+        ctx = onet.Ctx(train=False)
+        o = onet.pose_forward(img, P, ctx)
+        of = onet.pose_forward(torch.flip(img, dims=[-1]), P, ctx)
+        hm = odec.flip_merge(o["heatmaps"].numpy(), of["heatmaps"].numpy(), flip_pairs)
+        if "offsets" in o:
+            return odec.fusion_decode(hm, o["offsets"].numpy(), float(P["head.subpixel_refine.alpha"]), float(torch.sigmoid(P["head.fusion_weight"])))
+        return odec.argmax_decode(hm)
+
+
+def time_flip_inference(spec, flip_pairs, B=4, steps=3, warmup=1, input_size=(288, 384), threads=None):
+    """-> (images/sec, threads used): flip-test inference of the CPU oracle, fp32."""
+    if threads:
+        torch.set_num_threads(threads)
+    P = init_params(spec)
+    W, H = input_size
+    img = torch.from_numpy(np.random.default_rng(1234).standard_normal((B, 3, H, W)).astype(np.float32))
+    for _ in range(warmup):
+        flip_inference(P, img, flip_pairs)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        flip_inference(P, img, flip_pairs)
+    dt = time.perf_counter() - t0
+    return B * steps / dt, torch.get_num_threads()

@@ -47,6 +47,7 @@ struct IgemmArgs {
     int out_mode;             // 0 bf16 row-major, 1 fp32 row-major, 2 fp32 NCHW planes [B][N][Ho*Wo]
     int xcd_remap;            // set by igemm_launch (PK_IGEMM_XCD=0 disables the XCD-contiguous tile order)
     int vec8;                 // set by igemm_launch: row-major pointers 16-byte aligned and ldo % 8 == 0 -> 16-byte epilogue I/O
+    int chunk_major;          // set by igemm_launch: K order = all taps of one channel chunk back to back (N <= 32 tiles of deep 3x3 convs)
 };
 
 // ================================================================================================ main kernel (v2)
@@ -312,7 +313,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     // (Measured and dropped: chunk-major order -- all nine taps of one channel chunk back to back, so that the shifted re-reads of the
     // same pixels stay in L2 instead of cycling ~11 MB per XCD between two taps (PMC: the head conv fetches 4.1x its input).  The row
     // offsets must then be recomputed every step: head conv forward 335 -> 400 us, dgrad 290 -> 360 us; only N = 32 tiles gained.)
+    // ... kept for BN = 32 with nine taps and >= 128 input channels (p.chunk_major, set by igemm_launch): 3x3 256 -> 32 @64x48 fetched
+    // 681 MB for its 100 MB input at 5.8 TB/s of fabric traffic, 118 us.)
     auto advance = [&]() {                // next (tap, chunk) in contraction order; recomputes the row offsets on a tap change
+        if (BN == 32 && p.chunk_major) {
+            if (++t_next == p.T) {
+                t_next = 0;
+                c_next += BK;
+            }
+            set_tap(t_next);
+            return;
+        }
         c_next += BK;
         if (c_next >= p.Cin) {
             c_next = 0;
@@ -651,12 +662,14 @@ __global__ void __launch_bounds__(512, 2) k_conv8p(IgemmArgs p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (__attribute__((address_space(3))) void*)(sp + 8192 + i * 4096), 16, wo[i],
                                                      (q_tap * p.Cin + q_c0) * 2, 0, 0);
 #endif
-        q_c0 += 32;
-        if (q_c0 >= p.Cin) {
-            q_c0 = 0;
-            ++q_tap;
-            set_tap();
+        // chunk-major K order: the nine taps of one 32-channel chunk back to back -- the shifted re-reads of the same pixel rows (64
+        // bytes each) hit the XCD's L2 instead of cycling the whole 256-channel rows through it between two taps (PMC, tap-major:
+        // 394 MB fetched for 100 MB of input).  A tap change costs this kernel two scalars, no per-row address work.
+        if (++q_tap == p.T) {
+            q_tap = 0;
+            q_c0 += 32;
         }
+        set_tap();
     };
 
     // ---- fragment addresses: row (lane & 15) of a 16-row block, logical chunk lane >> 4, swizzled; blocks are 1024 bytes apart
@@ -785,12 +798,39 @@ static inline bool conv8p_takes(const IgemmArgs& a) {
            a.ldo == a.N && (((uintptr_t)a.out) & 15) == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= min_tiles && a.Hs == a.Ho && a.Ws == a.Wo;
 }
 
+// PK_IGEMM_LOG=1: the launch shapes of a run, counted on the host and printed at exit (profiling aid)
+#include <map>
+#include <string>
+static std::map<std::string, int>& igemm_log() {
+    static std::map<std::string, int>* m = new std::map<std::string, int>();      // leaked on purpose: read by an atexit handler
+    return *m;
+}
+static void igemm_log_dump() {
+    for (auto& kv : igemm_log()) fprintf(stderr, "# igemm %6d x %s\n", kv.second, kv.first.c_str());
+}
+static void igemm_log_add(const IgemmArgs& a) {
+    static const bool on = getenv("PK_IGEMM_LOG") && atoi(getenv("PK_IGEMM_LOG"));
+    if (!on) return;
+    static bool reg = false;
+    if (!reg) {
+        reg = true;
+        atexit(igemm_log_dump);
+    }
+    char buf[200];
+    snprintf(buf, sizeof buf, "M=%-7d N=%-4d Cin=%-4d T=%d s=%d dil=%d conv=%d amap=%d omap=%d res=%d stats=%d act=%d gelu_of=%d out_mode=%d", a.M, a.N, a.Cin, a.T,
+             a.stride, a.dilated, a.Ho > 0, a.a_rowmap != nullptr, a.o_rowmap != nullptr, a.res != nullptr, a.stats != nullptr, a.act,
+             a.gelu_of != nullptr, a.out_mode);
+    igemm_log()[buf]++;
+}
 static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) {
     IgemmArgs a = a_in;
+    igemm_log_add(a);
     a.vec8 = (a.ldo % 8) == 0 &&
              ((((uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.preact | (uintptr_t)a.gelu_of) & 15) == 0);
     static const int xcd_on = getenv("PK_IGEMM_XCD") ? atoi(getenv("PK_IGEMM_XCD")) : 1;
     a.xcd_remap = xcd_on;
+    static const int cm_on = getenv("PK_IGEMM_CHUNK_MAJOR") ? atoi(getenv("PK_IGEMM_CHUNK_MAJOR")) : 1;
+    a.chunk_major = cm_on && a.T == 9 && a.N <= 32 && a.Cin >= 128 && (a.Cin % 64) == 0;
     if (conv8p_takes(a)) {
         hipLaunchKernelGGL(k_conv8p, dim3((unsigned)(((a.M + 255) / 256) * (a.N / 256))), dim3(512), 0, st, a);
         return pk_launch_status(who);
@@ -1880,7 +1920,9 @@ struct ReduceDesc { const float* part; float* out; int64_t slab_stride; int S, K
 // (the first version read 64-byte pieces and ran at a quarter of the HBM rate: 1.17 ms per step for ~1.5 GB of slabs.  Measured and
 // dropped in round 2: 1 KiB contiguous per slab row x 4 slab-lanes with four rows in flight per lane -- 1 310 us instead of 686 us;
 // and, for the 3x3 weights whose OIHW destination is written one float every 36 bytes, a block per (n, 64 channels, nine taps) with
-// the destination run transposed through LDS and written contiguously -- step 18.3 -> 18.56 ms.)
+// the destination run transposed through LDS and written contiguously -- step 18.3 -> 18.56 ms.  Round 3: four independent loads per
+// thread and round (rows k, k+16, k+32, k+48) -- unchanged, 637 us for the step's 2.29 GB = 3.6 TB/s; four 64-output groups per workgroup
+// (45 000 workgroups instead of 180 000, four loads in flight per thread) -- 1 072 us.)
 __global__ void __launch_bounds__(256) k_reduce_many(const ReduceDesc* __restrict__ desc, const int* __restrict__ blk_desc,
                                                      const int* __restrict__ blk_first) {
     __shared__ float4 sh[16][17];

@@ -19,14 +19,16 @@ from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, ma
 class WindowAttentionParams(nn.Module):
     """qkv/proj + relative-position table (169, heads) + the (49,49) index buffer (hrformer.py:147-170)."""
 
-    def __init__(self, dim, heads, ws=7):
+    def __init__(self, dim, heads, ws=7, with_rpe=True):
         super().__init__()
-        self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 2, heads))
-        nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
-        ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
-        ys, xs = ys.reshape(-1), xs.reshape(-1)
-        self.register_buffer("relative_position_index",
-                             (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1))
+        self.with_rpe = with_rpe
+        if with_rpe:                           # hrformer.py:148-170: without it the module holds neither the table nor the index buffer
+            self.relative_position_bias_table = nn.Parameter(torch.zeros((2 * ws - 1) ** 2, heads))
+            nn.init.trunc_normal_(self.relative_position_bias_table, std=0.02)
+            ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
+            ys, xs = ys.reshape(-1), xs.reshape(-1)
+            self.register_buffer("relative_position_index",
+                                 (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1))
         self.qkv = nn.Linear(dim, dim * 3)
         self.proj = nn.Linear(dim, dim)
         self.num_heads = heads
@@ -53,11 +55,11 @@ class MlpParams(nn.Module):
 
 
 class HRFormerBlock(nn.Module):
-    def __init__(self, dim, heads, mlp_ratio=4.0, drop_path=0.0):
+    def __init__(self, dim, heads, mlp_ratio=4.0, drop_path=0.0, with_rpe=True):
         super().__init__()
         self.dim, self.heads, self.drop_prob = dim, heads, float(drop_path)
         self.norm1 = nn.LayerNorm(dim)
-        self.attn = WindowAttentionParams(dim, heads)
+        self.attn = WindowAttentionParams(dim, heads, with_rpe=with_rpe)
         self.norm2 = nn.LayerNorm(dim)
         self.mlp = MlpParams(dim, int(dim * mlp_ratio))
 
@@ -77,10 +79,10 @@ _CHAIN = os.environ.get("POSE_CHAIN_MODULES", "1") != "0"
 
 
 class HRFormerModule(nn.Module):
-    def __init__(self, channels, heads, blocks_per_branch, mlp_ratios, drop_path):
+    def __init__(self, channels, heads, blocks_per_branch, mlp_ratios, drop_path, with_rpe=True):
         super().__init__()
         self.branches = nn.ModuleList(
-            nn.ModuleList(HRFormerBlock(c, h, r, drop_path) for _ in range(nb))
+            nn.ModuleList(HRFormerBlock(c, h, r, drop_path, with_rpe) for _ in range(nb))
             for c, h, nb, r in zip(channels, heads, blocks_per_branch, mlp_ratios))
         if len(channels) > 1:
             self.fuse_layers = make_fuse_layers(channels)
@@ -136,8 +138,6 @@ class HRFormer(nn.Module):
                  stage4_window_sizes=(7, 7, 7, 7)):
         super().__init__()
         self._ctor = {k: v for k, v in locals().items() if k not in ("self", "__class__")}      # to rebuild a padded twin (models/padded.py)
-        if not with_rpe:
-            raise ValueError("with_rpe=False is not supported by the fused window-attention kernels")
         for ws in (*stage2_window_sizes, *stage3_window_sizes, *stage4_window_sizes):
             if ws != 7:
                 raise ValueError("window size must be 7")
@@ -152,7 +152,7 @@ class HRFormer(nn.Module):
                                                   (stage3_num_modules, stage3_num_channels, stage3_num_heads, stage3_num_blocks, stage3_mlp_ratios),
                                                   (stage4_num_modules, stage4_num_channels, stage4_num_heads, stage4_num_blocks, stage4_mlp_ratios)), start=2):
             setattr(self, f"transition{s - 1}", make_transition(pre, list(ch)))
-            setattr(self, f"stage{s}", nn.ModuleList(HRFormerModule(list(ch), list(hd), list(nb), list(mr), drop_path_rate) for _ in range(nm)))
+            setattr(self, f"stage{s}", nn.ModuleList(HRFormerModule(list(ch), list(hd), list(nb), list(mr), drop_path_rate, with_rpe) for _ in range(nm)))
             pre = list(ch)
         self.out_channels = stage4_num_channels[0]
         init_backbone_weights(self)

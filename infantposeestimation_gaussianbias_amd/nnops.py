@@ -778,8 +778,24 @@ class _MlpOnly(torch.autograd.Function):
         return dx, dw1, db1, dw2, db2
 
 
+_ZERO_TABLES = {}
+
+
+def rel_table(attn, heads):
+    """The (169, heads) relative-position-bias table of a WindowAttention module; `with_rpe=False` modules (hrformer.py:145-191) have
+    none: the kernels then add a constant all-zero table (its gradient is computed and dropped)."""
+    t = getattr(attn, "relative_position_bias_table", None)
+    if t is not None:
+        return t
+    dev = attn.qkv.weight.device
+    key = (str(dev), heads)
+    if key not in _ZERO_TABLES:
+        _ZERO_TABLES[key] = torch.zeros(169, heads, dtype=F32, device=dev)
+    return _ZERO_TABLES[key]
+
+
 def window_attention_tokens(tok, attn, heads):
-    return _WindowAttnOnly.apply(tok, attn.relative_position_bias_table, attn.qkv.weight, attn.qkv.bias, attn.proj.weight, attn.proj.bias, heads)
+    return _WindowAttnOnly.apply(tok, rel_table(attn, heads), attn.qkv.weight, attn.qkv.bias, attn.proj.weight, attn.proj.bias, heads)
 
 
 def mlp_rows(x2d, mlp):
@@ -941,13 +957,13 @@ def window_block(x, blk, heads, scale1=None, scale2=None):
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or blk.norm1.weight.requires_grad)
     if fused_attn_enabled(x.shape[-1], heads, c_real, attn_scale, train=needs_grad):
         if needs_grad:
-            x = _AttnHalfFused.apply(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+            x = _AttnHalfFused.apply(x, blk.norm1.weight, blk.norm1.bias, rel_table(a, heads), a.qkv.weight, a.qkv.bias,
                                      a.proj.weight, a.proj.bias, scale1, heads)
         else:
-            x = attn_half_fused_forward(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+            x = attn_half_fused_forward(x, blk.norm1.weight, blk.norm1.bias, rel_table(a, heads), a.qkv.weight, a.qkv.bias,
                                         a.proj.weight, a.proj.bias, scale1, heads)[0]
     else:
-        x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, a.relative_position_bias_table, a.qkv.weight, a.qkv.bias,
+        x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, rel_table(a, heads), a.qkv.weight, a.qkv.bias,
                             a.proj.weight, a.proj.bias, scale1, heads, c_real, attn_scale)
     m = blk.mlp
     if fused_mlp_enabled(x.shape[-1], c_real) and m.fc1.weight.shape[0] == 4 * x.shape[-1]:
@@ -1061,8 +1077,8 @@ def supported(model) -> bool:
                 return False
             if m.weight.shape[1] % 8 and m.weight.shape[1] != 3:
                 return False
-        if hasattr(m, "relative_position_bias_table"):
-            d = m.qkv.weight.shape[1] // m.relative_position_bias_table.shape[1]
+        if hasattr(m, "qkv") and hasattr(m, "num_heads"):
+            d = m.qkv.weight.shape[1] // m.num_heads
             if d > 64 or d % 8:
                 return False
         if isinstance(m, torch.nn.LayerNorm) and m.normalized_shape[0] % 8:

@@ -166,7 +166,10 @@ def rel_bias(P, pre, heads, ws=WS):
     ys, xs = torch.meshgrid(torch.arange(ws), torch.arange(ws), indexing="ij")
     ys, xs = ys.reshape(-1), xs.reshape(-1)
     idx = (ys[:, None] - ys[None, :] + ws - 1) * (2 * ws - 1) + (xs[:, None] - xs[None, :] + ws - 1)
-    return P[pre + ".relative_position_bias_table"][idx.reshape(-1)].reshape(ws * ws, ws * ws, heads).permute(2, 0, 1)
+    table = P.get(pre + ".relative_position_bias_table")
+    if table is None:                    # with_rpe=False (hrformer.py:186-191): no bias term
+        return torch.zeros(heads, ws * ws, ws * ws)
+    return table[idx.reshape(-1)].reshape(ws * ws, ws * ws, heads).permute(2, 0, 1)
 
 
 def window_attention(tok, P, pre, heads, ctx=None):

@@ -49,7 +49,7 @@ class Holder(torch.nn.Module):
 
 def conv_cases(flt):
     B = 64
-    for (H, W, Cin, Cout, k, s) in [(64, 48, 256, 256, 3, 1), (64, 48, 256, 128, 3, 1), (64, 48, 32, 256, 3, 1), (64, 48, 64, 64, 3, 1),
+    for (H, W, Cin, Cout, k, s) in [(64, 48, 256, 256, 3, 1), (64, 48, 256, 128, 3, 1), (64, 48, 256, 32, 3, 1), (64, 48, 32, 256, 3, 1), (64, 48, 64, 64, 3, 1),
                                     (64, 48, 64, 256, 1, 1), (64, 48, 256, 64, 1, 1), (128, 96, 64, 64, 3, 2), (256, 192, 8, 64, 3, 2),
                                     (32, 24, 64, 64, 3, 1), (64, 48, 32, 64, 3, 2)]:
         name = f"conv {Cin}->{Cout} k{k} s{s} @{H}x{W}"

@@ -1,5 +1,4 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"
-for g in 256 100000 512 384 256 100000; do
-  PK_CONV8P_GRID=$g timeout -k 10 200 python scripts/bench_kernels.py "conv 256->256" 2>&1 | grep "dgrad\|fwd" | sed "s/^/grid=$g  /"
-done
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout -k 10 300 python -m pytest tests/test_gpu_network_ops.py -m gpu -q -x --timeout 300 -k "conv" 2>&1 | tail -2
+for v in 1 0 1 0; do PK_IGEMM_CHUNK_MAJOR=$v timeout -k 10 200 python scripts/bench_kernels.py "conv 256->32" 2>&1 | grep "fwd\|dgrad" | sed "s/^/cm=$v /"; done

@@ -1263,3 +1263,29 @@ def test_fusion_loss_without_target_weight_vs_golden(golden):
     out["total_loss"].backward()
     for t, k in ((hm, "g_hm"), (off, "g_off"), (var, "g_var")):
         assert rel_err(C(t.grad), z[k]) < 2e-4, k
+
+
+def test_hrformer_without_relative_position_bias_vs_golden(golden):
+    """with_rpe=False (hrformer.py:145-191): block forward + input / qkv-weight gradients (the unfused C = 64 training path and the fused
+    forward) and the whole small-width backbone in eval mode against the vectors captured from the reference."""
+    from infantposeestimation_gaussianbias_amd.models import hrformer
+    from recipe import synth_input, synth_state_dict
+    z, specs = golden("norpe_r03.npz"), golden("norpe_r03.json")
+    blk = hrformer.HRFormerBlock(64, 2, 4.0, 0.0, with_rpe=False)
+    blk.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(specs["block_spec"], 48).items()}, strict=True)
+    blk = blk.to(DEV).train()
+    x = G(synth_input("norpe_blk", (2, 64, 9, 10))).requires_grad_(True)
+    y = blk(x)
+    assert rel_err(C(y), z["blk_out"]) < 2e-2
+    y.float().backward(G(synth_input("norpe_blk_gy", tuple(y.shape))))
+    assert rel_err(C(x.grad), z["blk_gx"]) < 3e-2 and rel_err(C(blk.attn.qkv.weight.grad), z["blk_gqkv"]) < 3e-2
+    with torch.no_grad():
+        assert rel_err(C(blk.eval()(x.detach())), z["blk_out"]) < 2e-2                  # fused forward kernels (eval)
+    bb = hrformer.HRFormer(with_rpe=False, in_channels=3, drop_path_rate=0.0, stage2_num_channels=(32, 64), stage2_num_heads=(1, 2),
+                           stage3_num_channels=(32, 64, 128), stage3_num_heads=(1, 2, 4), stage4_num_channels=(32, 64, 128, 256),
+                           stage4_num_heads=(1, 2, 4, 8))
+    bb.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(specs["backbone_spec"], 47).items()}, strict=True)
+    bb = bb.to(DEV).eval()
+    with torch.no_grad():
+        out = bb(G(synth_input("norpe_bb", (1, 3, 64, 64))))
+    assert rel_err(C(out), z["bb_out"]) < 3e-2

@@ -74,6 +74,17 @@ def test_state_dict_contract(golden, name, bb, K, head):
     m.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec, 1).items()}, strict=True)
 
 
+def test_state_dict_contract_without_relative_position_bias(golden):
+    """HRFormer(with_rpe=False) (hrformer.py:145-191): no table parameter, no index buffer -- keys, order, shapes as the reference's."""
+    from infantposeestimation_gaussianbias_amd.models import hrformer
+    from recipe import spec_of
+    spec = golden("norpe_r03.json")["backbone_spec"]
+    m = hrformer.HRFormer(with_rpe=False, in_channels=3, drop_path_rate=0.0, stage2_num_channels=(32, 64), stage2_num_heads=(1, 2),
+                          stage3_num_channels=(32, 64, 128), stage3_num_heads=(1, 2, 4), stage4_num_channels=(32, 64, 128, 256),
+                          stage4_num_heads=(1, 2, 4, 8))
+    assert spec_of(m.state_dict()) == spec and not any("relative_position" in k for k in spec)
+
+
 def test_unknown_backbone_raises():
     from infantposeestimation_gaussianbias_amd.models import PoseEstimator
     with pytest.raises(ValueError, match="Unknown backbone"):

@@ -11,7 +11,7 @@ import pytest
 import torch
 
 from conftest import rel_err
-from recipe import synth_state_dict
+from recipe import synth_input, synth_state_dict
 from oracle import decode as odec
 from oracle import losses as olos
 from oracle import nets as onet
@@ -444,3 +444,19 @@ def test_fusion_loss_without_target_weight_vs_reference(golden):
     out["total_loss"].backward()
     for t, k in ((hm, "g_hm"), (off, "g_off"), (var, "g_var")):
         assert np.abs(t.grad.numpy() - z[k]).max() <= 1e-4 * max(1e-6, np.abs(z[k]).max()), k
+
+
+def test_block_without_relative_position_bias_vs_reference(golden):
+    """HRFormerBlock(with_rpe=False) (hrformer.py:145-191, 262-293): the oracle without the bias term against the reference's output, input
+    gradient and qkv weight gradient (tests/golden/make_golden_r03.py)."""
+    from oracle import nets as onet
+    z, spec = golden("norpe_r03.npz"), golden("norpe_r03.json")["block_spec"]
+    assert not any("relative_position" in k for k in spec)
+    P = {k: torch.from_numpy(v).clone() for k, v in synth_state_dict(spec, 48).items()}
+    P["attn.qkv.weight"].requires_grad_(True)
+    x = torch.from_numpy(synth_input("norpe_blk", (2, 64, 9, 10))).requires_grad_(True)
+    y = onet.hrformer_block(x.permute(0, 2, 3, 1), {"b." + k: v for k, v in P.items()}, "b", 2, onet.Ctx()).permute(0, 3, 1, 2)
+    assert np.abs(y.detach().numpy() - z["blk_out"]).max() <= 1e-5 * np.abs(z["blk_out"]).max()
+    y.backward(torch.from_numpy(synth_input("norpe_blk_gy", tuple(y.shape))))
+    assert np.abs(x.grad.numpy() - z["blk_gx"]).max() <= 1e-4 * np.abs(z["blk_gx"]).max()
+    assert np.abs(P["attn.qkv.weight"].grad.numpy() - z["blk_gqkv"]).max() <= 1e-4 * np.abs(z["blk_gqkv"]).max()

@@ -897,6 +897,18 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
             for (int h = 0; h < HEADS; ++h) {
                 // ---- token-form operands: lane = token, slots = head channel e = 16 (jj >> 2) + 4g + (jj & 3)
                 bf16x8 qf[4], kf[4], vf[4], dof[4];
+                // the saved attention output and log-sum-exp of all four token tiles are requested up front (PMC: the waves of this kernel
+                // sat parked on s_waitcnt 58 % of their cycles -- one dependent round trip per tile right where the value was needed)
+                u32x2 osv[4][2];
+                float lsv[4];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int i = 16 * t + i16;
+                    const unsigned ob = i < AT_N ? (unsigned)((w * AT_N + i) * C + 32 * h + 4 * g) * 2u : OOB_OFF;
+                    osv[t][0] = __builtin_amdgcn_raw_buffer_load_b64(rs, ob, 0, 0);
+                    osv[t][1] = __builtin_amdgcn_raw_buffer_load_b64(rs, i < AT_N ? ob + 32 : OOB_OFF, 0, 0);
+                    lsv[t] = i < AT_N ? p.lse[((size_t)w * HEADS + h) * AT_N + i] : 0.f;
+                }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
                     f32x4 a[4][2];      // [q, k, v, dO][et]
@@ -919,15 +931,13 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                     dof[t] = pack2(a[3][0], a[3][1]);
                     // delta_i = sum_e dO[i][e] O[i][e]: this lane's 8 channels of token i = 16t + i16, then the 4 lanes of the token
                     const int i = 16 * t + i16;
-                    const unsigned ob = i < AT_N ? (unsigned)((w * AT_N + i) * C + 32 * h + 4 * g) * 2u : OOB_OFF;
-                    const f32x4 o0 = unpack4(__builtin_amdgcn_raw_buffer_load_b64(rs, ob, 0, 0));
-                    const f32x4 o1 = unpack4(__builtin_amdgcn_raw_buffer_load_b64(rs, i < AT_N ? ob + 32 : OOB_OFF, 0, 0));
+                    const f32x4 o0 = unpack4(osv[t][0]), o1 = unpack4(osv[t][1]);
                     float de = 0.f;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) de += a[3][0][r] * o0[r] + a[3][1][r] * o1[r];
                     de = xor16_sum(de);
                     de = xor32_sum(de);
-                    const float l = i < AT_N ? p.lse[((size_t)w * HEADS + h) * AT_N + i] : 0.f;
+                    const float l = lsv[t];
                     if (g == 0) {
                         sLse[wave][i] = l;
                         sDelta[wave][i] = de;

@@ -159,8 +159,18 @@ __device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo
     }
 }
 
-template <int BM, int BN, int WM, int WN, int BK>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_igemm2(IgemmArgs p) {
+// LEAN = 1: the token GEMMs of the HRFormer blocks only (linear rows with optional gather / scatter maps, bias, residual with a per-sample
+// scale, bf16 output) -- the convolution addressing, the activations, the fp32 / NCHW outputs and the statistics are compiled out.  The
+// full kernel is 27-30 KB of code; a small launch (100-900 workgroups, 1-4 K-steps) spends much of its few microseconds fetching it cold.
+template <int BM, int BN, int WM, int WN, int BK, int LEAN = 0>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_igemm2(IgemmArgs p_in) {
+    IgemmArgs p = p_in;
+    if (LEAN) {                      // LEAN = 2 keeps the GELU epilogues (fc1: GELU + saved pre-activation; fc2 data gradient: x gelu'(z))
+        p.stats = nullptr;
+        p.out_mode = 0; p.T = 1; p.Ho = 0; p.Wo = 0; p.dilated = 0; p.vec8 = 1; p.chunk_major = 0;
+        if (LEAN == 1) { p.preact = nullptr; p.gelu_of = nullptr; p.act = 0; }
+        else if (p.act != 1) p.act = 0;
+    }
     constexpr int MI = BM / WM / 16, NI = BN / WN / 16;
     constexpr int CH = BK / 8;                       // 16-byte chunks per tile row
     constexpr int A_PT = BM * CH / 256;              // A chunks per thread (2 or 4)
@@ -847,6 +857,9 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
         return pk_launch_status(who);
     }
     const bool k64 = (a.Cin % 64) == 0;              // deeper K-chunks when the channel count allows full 64-wide tiles
+    static const int lean_on = getenv("PK_IGEMM_LEAN") ? atoi(getenv("PK_IGEMM_LEAN")) : 1;
+    const bool lean_any = lean_on && a.T == 1 && a.Ho == 0 && !a.stats && a.act <= 1 && a.out_mode == 0 && a.vec8 && k64 && (a.N % 8) == 0;
+    const bool lean = lean_any && !a.preact && !a.gelu_of && a.act == 0, lean_g = lean_any && !lean;
     // Shallow contractions (K = T*Cin <= 256: the token-MLP / qkv GEMMs) are bound by their output traffic, not MFMA:
     // 128x64 tiles need half the accumulators (4 waves/SIMD instead of 2) and hide the epilogue's memory latency better
     // (measured 24 vs 32 us for qkv K=32 N=96, 43 vs 51 us for fc1+GELU K=32 N=128, 17 vs 21 us for K=128 N=512).
@@ -856,16 +869,22 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     static const int smallm_on = getenv("PK_IGEMM_SMALLM") ? atoi(getenv("PK_IGEMM_SMALLM")) : 1;
     const bool small_m = smallm_on && a.N > 64 && (long)gm * ((a.N + 127) / 128) < 512;
     if (small_m && (long)gm * ((a.N + 63) / 64) < 512 && !a.stats) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
+        if (lean) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64, 1>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
+        else if (lean_g) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64, 2>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
+        else if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
         else hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 32>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
     } else if (a.N > 64 && (a.T * a.Cin <= 256 || small_m) && !a.stats) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        if (lean) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 1>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        else if (lean_g) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 2>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        else if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
         else hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
     } else if (a.N > 64) {
         if (k64) hipLaunchKernelGGL((k_igemm2<128, 128, 2, 2, 64>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
         else hipLaunchKernelGGL((k_igemm2<128, 128, 2, 2, 32>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
     } else if (a.N > 32) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
+        if (lean) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 1>), dim3(gm, 1), block, 0, st, a);
+        else if (lean_g) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 2>), dim3(gm, 1), block, 0, st, a);
+        else if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
         else hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
     } else {
         if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);

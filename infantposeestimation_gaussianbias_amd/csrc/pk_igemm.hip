@@ -2038,10 +2038,12 @@ static inline void wgrad4_tile(int N, int Cin, int kind, int& tn, int& tc) {
 // padded-pixel count of the 3x3 form (the K range of k_wgrad4_3x3); M = B * Hs * Ws
 static inline int wgrad4_rows(int M, int Hs, int Ws, int kind) { return kind == 2 ? (M / (Hs * Ws)) * (Hs + 2) * (Ws + 2) : M; }
 static int wgrad4_slices(int rows, int N, int Cin, int kind) {
-    // two workgroups per CU (single tap) / one (3x3: nine accumulator sets), slices of >= 256 rows (512 and 1 024 measured: within noise)
+    // two workgroups per CU (single tap) / one (3x3: nine accumulator sets), slices of >= 512 rows: against 256 the step is unchanged
+    // (17.3 / 17.6 ms on two boxes either way) and the slabs of the low-resolution branches halve (k_reduce_many 653 -> 570 us isolated);
+    // 1 024 rows starve the small launches of workgroups (step + 0.6 ms)
     static const int t1 = getenv("PK_WGRAD4_WGS") ? atoi(getenv("PK_WGRAD4_WGS")) : 512;
     static const int t9 = getenv("PK_WGRAD4_WGS9") ? atoi(getenv("PK_WGRAD4_WGS9")) : 256;
-    static const int min_rows = getenv("PK_WGRAD4_ROWS") ? atoi(getenv("PK_WGRAD4_ROWS")) : 256;
+    static const int min_rows = getenv("PK_WGRAD4_ROWS") ? atoi(getenv("PK_WGRAD4_ROWS")) : 512;
     int tn, tc;
     wgrad4_tile(N, Cin, kind, tn, tc);
     const int tiles = ((N + tn - 1) / tn) * (((kind == 3 ? 9 * Cin : Cin) + tc - 1) / tc);

@@ -856,7 +856,11 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
         hipLaunchKernelGGL((k_igemm2<256, 128, 2, 2, 32>), dim3((a.M + 255) / 256, a.N / 128), block, 0, st, a);
         return pk_launch_status(who);
     }
-    const bool k64 = (a.Cin % 64) == 0;              // deeper K-chunks when the channel count allows full 64-wide tiles
+    // deeper K-chunks when the channel count allows full 64-wide tiles -- except for contractions of <= 128 (one or two steps): the BK = 32
+    // variants hold half the LDS and run 4-7 waves per SIMD instead of 3, which is what an output-bound launch needs (1x1 64 -> 256 @64x48
+    // data gradient 48.5 -> 37 us)
+    static const int shallow32 = getenv("PK_IGEMM_SHALLOW32") ? atoi(getenv("PK_IGEMM_SHALLOW32")) : 128;
+    const bool k64 = (a.Cin % 64) == 0 && !(a.T * a.Cin <= shallow32);
     static const int lean_on = getenv("PK_IGEMM_LEAN") ? atoi(getenv("PK_IGEMM_LEAN")) : 1;
     const bool lean_any = lean_on && a.T == 1 && a.Ho == 0 && !a.stats && a.act <= 1 && a.out_mode == 0 && a.vec8 && k64 && (a.N % 8) == 0;
     const bool lean = lean_any && !a.preact && !a.gelu_of && a.act == 0, lean_g = lean_any && !lean;
@@ -873,7 +877,7 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
         else if (lean_g) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64, 2>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
         else if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
         else hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 32>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
-    } else if (a.N > 64 && (a.T * a.Cin <= 256 || small_m) && !a.stats) {
+    } else if (a.N > 64 && (a.T * a.Cin <= 256 || small_m) && (!a.stats || a.T * a.Cin <= 256)) {       // (shallow convs with statistics too: 1x1 64 -> 256 forward 57 -> 47.6 us)
         if (lean) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 1>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
         else if (lean_g) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 2>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
         else if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);

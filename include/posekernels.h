@@ -152,6 +152,10 @@ int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, float* stats_
                    int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int dilated_input, int Ho, int Wo,
                    int act, int out_mode, const void* addend, void* stream);
 int pk_conv_stats_tiles(int M);
+/* Rows of the [rows][2][Cout] partial-statistics buffer a pk_conv2d_nhwc launch with bf16 output and statistics writes for this geometry
+ * (the 3x3 halo kernel emits one row per 64 padded positions; everything else pk_conv_stats_tiles(B*Ho*Wo)).  Replaces the per-call
+ * `torch.var_mean` inside nn.BatchNorm2d of the reference (models/hrnet.py:24-52): pk_bn_finalize sums the rows it is given. */
+int pk_conv_stats_rows(int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int Ho, int Wo);
 
 /* A1/A3 linear layers: nn.Linear qkv/proj (models/hrformer.py:167-169,180,197) and Mlp fc1/fc2 (:53-55,58-64).
  * out[o_rowmap[m]] = residual + res_scale[sample] * act(x[a_rowmap[m]] @ w^T + bias).  Row maps implement

@@ -796,6 +796,319 @@ __global__ void __launch_bounds__(512, 2) k_conv8p(IgemmArgs p) {
         if (m < p.M) *reinterpret_cast<u32x4*>(out + (size_t)m * p.ldo + n0 + wn * 64 + ch * 8) = v;
     }
 }
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+// ================================================================================================ halo kernel (small-channel 3x3 convs)
+// 3x3 stride-1 convolutions with 32 / 64 input and output channels on large maps (layer1, transitions and exchange units of HRFormer,
+// every BasicBlock of HRNet's high-resolution branches) are HBM-bound by arithmetic (64 -> 64 @64x48: 50 MB, 14.5 GFLOP) but ran at
+// 0.14 of the MFMA peak on k_igemm2: every tap re-stages the 128-row input tile through registers and LDS (9x the input through the
+// L2 -> LDS path, ~8 TB/s) and every workgroup re-reads the weights.  k_conv3h:
+//   * the K loop runs over PADDED pixel positions q = (b, py, px) of the zero-bordered (H+2) x (W+2) image (the trick of k_wgrad4_3x3):
+//     out[q] = sum_taps X[q + (kh-1)(W+2) + (kw-1)] . W[tap], so every tap of a tile of 128 consecutive positions is the SAME LDS tile read
+//     at a row offset -- the input tile plus a (W+3)-row halo either side goes global -> LDS ONCE per tile, by LDS-DMA, border positions
+//     fetched with the out-of-range offset (zeros); border outputs are computed and dropped;
+//   * the weights of a wave's output columns (all nine taps) live in REGISTERS for the whole kernel (144 VGPRs at 64 -> 64): waves as
+//     2 (positions) x 2 (channels), 64 positions x COUT/2 channels each;
+//   * persistent workgroups (two per CU) walk the tiles of one XCD's contiguous range; the DMA of tile i+1 flies under the MFMAs of tile i
+//     (two LDS buffers, one counted wait + two barriers per tile);
+//   * fragment addresses do not depend on the tile: nine per-tap base addresses per lane, computed once (the XOR swizzle term of a row is
+//     the same for all four 16-row blocks of a wave and both k-steps differ by one address bit).
+// Epilogue straight from the accumulators: interior positions only, optional addend; the BatchNorm statistics of a wave are kept in
+// registers over all its tiles and written once (one partial row per workgroup and position half: pk_conv_stats_rows).
+// Measured (B = 64, rocprof): 64 -> 64 @64x48 43.5 -> 30.8 us, @48x36 33 -> 22, 32 -> 32 @96x72 (B = 64) 38.5 -> 24.5, @16x12 15.3 -> 11.4.
+// Batch sweep of 64 -> 64 @64x48 (17.1 / 22.4 / 30.8 / 45.2 / 77.3 us at B = 16 / 32 / 64 / 128 / 256): ~11 us fixed (launch, 75 MB of
+// weight fragments into 2 048 waves' registers, first tiles' DMA, last stores) + ~5 us per tile slot; at B = 64 a workgroup walks 3 or
+// 4 tiles (1 650 tiles on 512 workgroups), so a quarter of the loop time is the fourth-tile tail.  Tried without effect: double-buffered
+// fragment reads (the LDS latency is hidden by the other workgroup of the CU), carried instead of divided DMA row coordinates, letting
+// a tile's stores drain under the next two tiles (kept: it is free), retiring the weight loads in front of the loop (kept: without it
+// the compiler's lazy waits sit inside the MFMA stream).
+template <int OFF>
+__device__ __forceinline__ bf16x8 h3_read(uint32_t lds_byte_addr) {
+    bf16x8 v;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(v) : "v"(lds_byte_addr), "n"(OFF) : "memory");
+    return v;
+}
+__device__ __forceinline__ int h3_div(int q, int d, float inv) {          // floor(q / d) for 0 <= q < 2^24: float estimate + one correction
+    int r = (int)((float)q * inv);
+    const int rem = q - r * d;
+    r += rem >= d ? 1 : (rem < 0 ? -1 : 0);
+    return r;
+}
+// s_waitcnt vmcnt(n) with a wave-uniform run-time n (the immediate is 6 bits: n > 63 waits for less than asked, which is always safe)
+__device__ __forceinline__ void h3_wait_vm(int n) {
+#define H3_W(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    switch (n < 0 ? 0 : (n > 63 ? 63 : n)) {
+        H3_W(0) H3_W(1) H3_W(2) H3_W(3) H3_W(4) H3_W(5) H3_W(6) H3_W(7) H3_W(8) H3_W(9) H3_W(10) H3_W(11) H3_W(12) H3_W(13) H3_W(14) H3_W(15)
+        H3_W(16) H3_W(17) H3_W(18) H3_W(19) H3_W(20) H3_W(21) H3_W(22) H3_W(23) H3_W(24) H3_W(25) H3_W(26) H3_W(27) H3_W(28) H3_W(29) H3_W(30) H3_W(31)
+        H3_W(32) H3_W(33) H3_W(34) H3_W(35) H3_W(36) H3_W(37) H3_W(38) H3_W(39) H3_W(40) H3_W(41) H3_W(42) H3_W(43) H3_W(44) H3_W(45) H3_W(46) H3_W(47)
+        H3_W(48) H3_W(49) H3_W(50) H3_W(51) H3_W(52) H3_W(53) H3_W(54) H3_W(55) H3_W(56) H3_W(57) H3_W(58) H3_W(59) H3_W(60) H3_W(61) H3_W(62) H3_W(63)
+    }
+#undef H3_W
+}
+template <int CIN, int COUT>
+__global__ void __launch_bounds__(256, 2) k_conv3h(IgemmArgs p, int pieces_per_wave) {
+    constexpr int RB = CIN * 2, CH = CIN / 8, RP = 1024 / RB, KS = CIN / 32, NI = COUT / 32;
+    extern __shared__ __attribute__((aligned(1024))) uint16_t h3_smem[];          // [2][pieces_per_wave * 4 KiB]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int H = p.Hs, W = p.Ws, W2 = W + 2, P = (H + 2) * W2, halo = W + 3;
+    const int nsamples = p.M / (H * W), Mp = nsamples * P;                        // padded positions of the whole batch
+    const int ntiles = (Mp + 127) >> 7;
+    const float invP = 1.f / (float)P, invW2 = 1.f / (float)W2;
+    const int bufbytes = pieces_per_wave * 4096;
+    // persistent workgroups, XCD-contiguous tile ranges (neighbouring tiles share their halo rows in L2)
+    int tile_first, tile_step, n_mine;
+    {
+        const int G = gridDim.x, L = blockIdx.x, q = ntiles >> 3, r = ntiles & 7, x = L & 7, j = L >> 3;
+        const int start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q, cnt = q + (x < r ? 1 : 0);
+        tile_step = (G - x + 7) >> 3;
+        tile_first = start + j;
+        n_mine = j < cnt ? (cnt - j + tile_step - 1) / tile_step : 0;
+    }
+    if (n_mine == 0) {          // (uneven XCD ranges can leave a workgroup without a tile: its statistics rows are zeros)
+        if (p.stats)
+            for (int i = tid; i < 4 * COUT; i += 256) p.stats[(size_t)blockIdx.x * 4 * COUT + i] = 0.f;
+        return;
+    }
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
+    const auto ro = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<uint16_t*>(p.out), 0, 0x7ffffff0, 0x00020000);
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.res ? p.res : p.x), 0, 0x7ffffff0, 0x00020000);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)h3_smem;
+
+    // ---- per-tap fragment base addresses (bytes from the start of a buffer): LDS row halo + 64 wm + (lane & 15) + tap offset, chunk lane >> 4
+    uint32_t fa[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int kh = t / 3, kw = t - kh * 3;
+        const int row = halo + wm * 64 + (lane & 15) + (kh - 1) * W2 + (kw - 1);
+        const int sw = CIN == 64 ? ((row >> 1) & 7) : (((row >> 3) & 1) << 1);
+        fa[t] = lds0 + (uint32_t)(row * RB + (((lane >> 4) ^ sw) & (CH - 1)) * 16);
+    }
+    // ---- DMA of the input tile + halo: buffer row j <-> padded position q0 - halo + j; 1 KiB pieces of RP rows, piece = wave + 4 i
+    const int prow = lane / CH, pchunk = lane % CH;
+    auto issue_tile = [&](int tile, int buf) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (b, py, px) of this lane's row in its first piece by two divisions, then carried from piece to piece (+ 4 RP positions)
+        const int q = tile * 128 - halo + wave * RP + prow;
+        int b = h3_div(q, P, invP);
+        const int rem = q - b * P;
+        int py = h3_div(rem, W2, invW2), px = rem - py * W2;
+        for (int i = 0; i < pieces_per_wave; ++i) {
+            const int piece = wave + 4 * i, j = piece * RP + prow;
+            const int sw = CIN == 64 ? ((j >> 1) & 7) : (((j >> 3) & 1) << 1);
+            const bool ok = b >= 0 && b < nsamples && py >= 1 && py <= H && px >= 1 && px <= W;
+            const unsigned off = ok ? (unsigned)((((b * H + py - 1) * W + px - 1) * CIN + ((pchunk ^ sw) & (CH - 1)) * 8) * 2) : OOB_OFF;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (__attribute__((address_space(3))) void*)(h3_smem + (buf * bufbytes + piece * 1024) / 2), 16, off, 0, 0, 0);
+            px += 4 * RP;
+            while (px >= W2) {
+                px -= W2;
+                if (++py == H + 2) {
+                    py = 0;
+                    ++b;
+                }
+            }
+        }
+#endif
+    };
+    f32x4 acc[NI][4];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    float ssum[NI][4], ssq[NI][4];              // BatchNorm statistics of this wave over ALL its tiles (lane: position lane % 16, channels 4 g ..)
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) ssum[ni][r] = ssq[ni][r] = 0.f;
+    // Vector-memory operations of one wave, in issue order: DMA(0) DMA(1) | DMA(2) ST(0) | DMA(3) ST(1) | ...  (iteration i computes tile
+    // i, then requests tile i+2 into the buffer it has just read, then stores tile i).  vmcnt counts loads AND stores in order, so the
+    // wait for DMA(i) at the top of iteration i names what may stay in flight behind it -- ST(i-2), DMA(i+1), ST(i-1): a tile's stores
+    // drain under the NEXT TWO tiles' MFMAs instead of stalling the next iteration (first version: wait for everything but DMA(i+1) --
+    // each tile paid an HBM write round trip).
+    // (only the NI * 4 output stores per tile are counted -- buffer-store intrinsics the backend cannot merge; the statistics stores and
+    // addend loads on top of them make the wave wait for MORE than it must, never less)
+    constexpr int n_st = NI * 4;
+    issue_tile(tile_first, 0);
+    if (n_mine > 1) issue_tile(tile_first + tile_step, 1);
+    // (the weight loads go out BEHIND the first two tiles' DMA: one memory round trip for both instead of two in a row)
+    // ---- weights of this wave's COUT/2 output channels, all nine taps, as MFMA A fragments (row = channel, 8 k-values per lane)
+    bf16x8 wreg[9][KS][NI];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                const int n = wn * (COUT / 2) + ni * 16 + (lane & 15);
+                wreg[t][ks][ni] = *reinterpret_cast<const bf16x8*>(p.w + ((size_t)n * 9 + t) * CIN + ks * 32 + (lane >> 4) * 8);
+            }
+    // The weight loads are retired HERE, through an asm that redefines every fragment: otherwise the compiler waits for them lazily at
+    // their first use INSIDE the tile loop -- counted vmcnt waits that, from the second tile on, wait for the DMA of the next tile and the
+    // stores of the previous one in the middle of the MFMAs (first version: 32 us, the DMA never overlapped the compute).
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) asm volatile("s_waitcnt vmcnt(0)" : "+v"(wreg[t][ks][ni])::"memory");
+    for (int it = 0; it < n_mine; ++it) {
+        const int tile = tile_first + it * tile_step, buf = it & 1;
+        {
+            int allow = 0;                                  // operations issued after DMA(it)
+            if (it + 1 < n_mine) allow += pieces_per_wave;  // DMA(it+1)
+            if (it >= 1) allow += n_st;                     // ST(it-1)
+            if (it >= 2) allow += n_st;                     // ST(it-2)
+            h3_wait_vm(allow);
+        }
+        asm volatile("s_barrier" ::: "memory");
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[ni][b] = zero;
+        const uint32_t boff = (uint32_t)(buf * bufbytes);
+        // 9 * KS steps of [4 fragment reads | 4 NI MFMAs]; the reads of step s+1 are issued before the MFMAs of step s (two fragment sets,
+        // a counted lgkmcnt(4) keeps the younger four in flight): the LDS latency of every step was exposed otherwise
+        bf16x8 pf[2][4];
+        {
+            const uint32_t a = fa[0] + boff;
+            pf[0][0] = h3_read<0>(a);
+            pf[0][1] = h3_read<16 * RB>(a);
+            pf[0][2] = h3_read<32 * RB>(a);
+            pf[0][3] = h3_read<48 * RB>(a);
+        }
+#pragma unroll
+        for (int st = 0; st < 9 * KS; ++st) {
+            const int t = st / KS, ks = st % KS, cur = st & 1;
+            if (st + 1 < 9 * KS) {
+                const int t2 = (st + 1) / KS, ks2 = (st + 1) % KS;
+                const uint32_t a = (fa[t2] + boff) ^ (ks2 ? 64u : 0u);
+                pf[cur ^ 1][0] = h3_read<0>(a);
+                pf[cur ^ 1][1] = h3_read<16 * RB>(a);
+                pf[cur ^ 1][2] = h3_read<32 * RB>(a);
+                pf[cur ^ 1][3] = h3_read<48 * RB>(a);
+                asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(pf[cur][0]), "+v"(pf[cur][1]), "+v"(pf[cur][2]), "+v"(pf[cur][3])::"memory");
+            } else {
+                c8_fence4(pf[cur][0], pf[cur][1], pf[cur][2], pf[cur][3]);
+            }
+#pragma unroll
+            for (int b = 0; b < 4; ++b)
+#pragma unroll
+                for (int ni = 0; ni < NI; ++ni) acc[ni][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[t][ks][ni], pf[cur][b], acc[ni][b], 0, 0, 0);
+        }
+        asm volatile("s_barrier" ::: "memory");          // every wave has finished reading this buffer ...
+        if (it + 2 < n_mine) issue_tile(tile + 2 * tile_step, buf);      // ... tile it+2 is requested into it
+        // ---- epilogue: lane (row g = lane / 16, position lane % 16 of block b) holds channels 16 ni + 4 g .. + 3; interior positions only
+        const int g = lane >> 4;
+        // (b, py, px) of this lane's position in block 0 by two divisions, carried to blocks 1-3 (+ 16 positions each)
+        int eb, epy, epx;
+        {
+            const int q = tile * 128 + wm * 64 + (lane & 15);
+            eb = h3_div(q, P, invP);
+            const int rem = q - eb * P;
+            epy = h3_div(rem, W2, invW2);
+            epx = rem - epy * W2;
+        }
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const bool ok = eb < nsamples && epy >= 1 && epy <= H && epx >= 1 && epx <= W;
+            const int m = (eb * H + epy - 1) * W + epx - 1;
+            epx += 16;
+            while (epx >= W2) {
+                epx -= W2;
+                if (++epy == H + 2) {
+                    epy = 0;
+                    ++eb;
+                }
+            }
+#pragma unroll
+            for (int ni = 0; ni < NI; ++ni) {
+                f32x4 v = acc[ni][b];
+                if (p.stats && ok) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        ssum[ni][r] += v[r];
+                        ssq[ni][r] += v[r] * v[r];
+                    }
+                }
+                const unsigned off = ok ? (unsigned)(m * COUT + wn * (COUT / 2) + ni * 16 + g * 4) * 2u : OOB_OFF;
+                if (p.res) {
+                    const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rr, off, 0, 0);
+                    v[0] += bf16_lo(rv[0]); v[1] += bf16_hi(rv[0]); v[2] += bf16_lo(rv[1]); v[3] += bf16_hi(rv[1]);
+                }
+                const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
+                __builtin_amdgcn_raw_buffer_store_b64(o, ro, off, 0, 0);
+            }
+        }
+    }
+    if (p.stats) {          // ONE partial row per (workgroup, position half): the sums of all its tiles, kept in registers until here
+        const int g = lane >> 4;
+        float* dst = p.stats + (size_t)(blockIdx.x * 2 + wm) * 2 * COUT + wn * (COUT / 2);
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sm = row16_sum(ssum[ni][r]), sq = row16_sum(ssq[ni][r]);
+                if ((lane & 15) == 0) {
+                    dst[ni * 16 + g * 4 + r] = sm;
+                    dst[COUT + ni * 16 + g * 4 + r] = sq;
+                }
+            }
+    }
+}
+static inline int pk_cu_count() {
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+static inline int conv3h_pieces_per_wave(int Ws, int Cin) {
+    const int R = 128 + 2 * (Ws + 3), RP = 1024 / (Cin * 2);
+    return ((R + RP - 1) / RP + 3) / 4;
+}
+static inline bool conv3h_takes(const IgemmArgs& a) {
+    const char* on_env = getenv("PK_CONV3H");
+    const char* mt_env = getenv("PK_CONV3H_MIN_TILES");
+    const bool on = !on_env || atoi(on_env) != 0;
+    const long min_tiles = mt_env ? atol(mt_env) : 96;         // (16x12 x 64 samples = 126 tiles: 11.4 us against 15.3 us on k_igemm2)
+    if (!(on && a.Ho > 0 && a.T == 9 && a.stride == 1 && !a.dilated && a.Hs == a.Ho && a.Ws == a.Wo && (a.Cin == 32 || a.Cin == 64) &&
+          (a.N == 32 || a.N == 64) && a.out_mode == 0 && !a.bias && !a.res_scale && !a.a_rowmap && !a.o_rowmap && !a.preact && !a.gelu_of &&
+          a.act == 0 && a.ldo == a.N && !(a.res && a.stats)))
+        return false;
+    const int pp = conv3h_pieces_per_wave(a.Ws, a.Cin);
+    if (pp < 3 || pp > 11) return false;                       // the counted vmcnt waits are compiled for 3 .. 11 pieces per wave (W <= ~96 at 64 channels)
+    const long Mp = (long)(a.M / (a.Hs * a.Ws)) * (a.Hs + 2) * (a.Ws + 2);
+    return Mp < (1 << 24) && (Mp + 127) / 128 >= min_tiles;
+}
+static inline int conv3h_grid(const IgemmArgs& a) {          // persistent workgroups: two per CU (the 64 -> 64 variant holds 232 VGPRs)
+    const long Mp = (long)(a.M / (a.Hs * a.Ws)) * (a.Hs + 2) * (a.Ws + 2);
+    const long ntiles = (Mp + 127) / 128;
+    return (int)(ntiles < 2L * pk_cu_count() ? ntiles : 2L * pk_cu_count());
+}
+static int conv3h_launch(const IgemmArgs& a, hipStream_t st, const char* who) {
+    const int pp = conv3h_pieces_per_wave(a.Ws, a.Cin);
+    const int lds = 2 * pp * 4096;
+    const int grid = conv3h_grid(a);
+#define C3H_GO(CI, CO)                                                                                                                        \
+    {                                                                                                                                         \
+        static bool attr_done = false;                                                                                                        \
+        if (!attr_done) {                                                                                                                     \
+            hipError_t e = hipFuncSetAttribute((const void*)k_conv3h<CI, CO>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 11 * 4096);     \
+            if (e != hipSuccess) {                                                                                                            \
+                pk_set_error("%s: cannot raise the LDS limit of k_conv3h: %s", who, hipGetErrorString(e));                                    \
+                return (int)e;                                                                                                                \
+            }                                                                                                                                 \
+            attr_done = true;                                                                                                                 \
+        }                                                                                                                                     \
+        hipLaunchKernelGGL((k_conv3h<CI, CO>), dim3((unsigned)grid), dim3(256), lds, st, a, pp);                                              \
+    }
+    if (a.Cin == 64 && a.N == 64) C3H_GO(64, 64)
+    else if (a.Cin == 64 && a.N == 32) C3H_GO(64, 32)
+    else if (a.Cin == 32 && a.N == 64) C3H_GO(32, 64)
+    else C3H_GO(32, 32)
+#undef C3H_GO
+    return pk_launch_status(who);
+}
+
 static inline bool conv8p_takes(const IgemmArgs& a) {
     // one workgroup per CU: below one full round of 256 tiles the 128 x 128 tiles of k_igemm2 spread the work over more CUs.
     // (both switches are read per call: the parity tests lower the tile count to run small and ragged shapes through this kernel)
@@ -841,6 +1154,7 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     a.xcd_remap = xcd_on;
     static const int cm_on = getenv("PK_IGEMM_CHUNK_MAJOR") ? atoi(getenv("PK_IGEMM_CHUNK_MAJOR")) : 1;
     a.chunk_major = cm_on && a.T == 9 && a.N <= 32 && a.Cin >= 128 && (a.Cin % 64) == 0;
+    if (conv3h_takes(a)) return conv3h_launch(a, st, who);
     if (conv8p_takes(a)) {
         hipLaunchKernelGGL(k_conv8p, dim3((unsigned)(((a.M + 255) / 256) * (a.N / 256))), dim3(512), 0, st, a);
         return pk_launch_status(who);
@@ -942,6 +1256,15 @@ extern "C" int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, fl
 }
 
 extern "C" int pk_conv_stats_tiles(int M) { return (M + STAT_ROWS - 1) / STAT_ROWS; }
+// rows of the [rows][2][Cout] partial-statistics buffer that pk_conv2d_nhwc(bf16 output, statistics) writes for this geometry: the halo
+// kernel emits one row per 64 PADDED positions, every other kernel one per 128 output pixels (pk_bn_finalize sums whatever it is given)
+extern "C" int pk_conv_stats_rows(int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int Ho, int Wo) {
+    IgemmArgs a{};
+    a.M = B * Ho * Wo; a.N = Cout; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo; a.stride = stride;
+    a.pad = ksize / 2; a.ldo = Cout; a.out_mode = 0; a.stats = reinterpret_cast<float*>(1);
+    if (conv3h_takes(a)) return 2 * conv3h_grid(a);
+    return pk_conv_stats_tiles(a.M);
+}
 
 extern "C" int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, const void* residual,
                               const float* res_scale, const int32_t* a_rowmap, const int32_t* o_rowmap, void* preact_out,

@@ -338,7 +338,7 @@ def _conv_raw(x, wf, Cout, ksize, stride, stats):
     raw = _e((B, Ho, Wo, Cout), BF16, x.device)
     part = None
     if stats:
-        tiles = _lib.lib.pk_conv_stats_tiles(B * Ho * Wo)
+        tiles = _lib.lib.pk_conv_stats_rows(B, Hs, Ws, Cin, Cout, ksize, stride, Ho, Wo)
         part = _e((tiles, 2, Cout), F32, x.device)
     call("pk_conv2d_nhwc", x, wf, raw, part, None, B, Hs, Ws, Cin, Cout, ksize, stride, 0, Ho, Wo, 0, 0, None, stream_ptr())
     return raw, part

@@ -51,7 +51,8 @@ def conv_cases(flt):
     B = 64
     for (H, W, Cin, Cout, k, s) in [(64, 48, 256, 256, 3, 1), (64, 48, 256, 128, 3, 1), (64, 48, 256, 32, 3, 1), (64, 48, 32, 256, 3, 1), (64, 48, 64, 64, 3, 1),
                                     (64, 48, 64, 256, 1, 1), (64, 48, 256, 64, 1, 1), (128, 96, 64, 64, 3, 2), (256, 192, 8, 64, 3, 2),
-                                    (32, 24, 64, 64, 3, 1), (64, 48, 32, 64, 3, 2)]:
+                                    (32, 24, 64, 64, 3, 1), (64, 48, 32, 64, 3, 2), (64, 48, 32, 32, 3, 1), (96, 72, 32, 32, 3, 1), (48, 36, 64, 64, 3, 1),
+                                    (16, 12, 64, 64, 3, 1), (32, 24, 32, 64, 3, 1), (32, 24, 64, 32, 3, 1)]:
         name = f"conv {Cin}->{Cout} k{k} s{s} @{H}x{W}"
         if flt and flt not in name:
             continue

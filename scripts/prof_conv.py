@@ -11,7 +11,7 @@ from infantposeestimation_gaussianbias_amd import nnops  # noqa: E402
 
 DEV, BF = "cuda", torch.bfloat16
 ITER = int(os.environ.get("ITER", "5"))
-B, H, W, C = 64, 64, 48, 256
+B, H, W, C = int(os.environ.get("PB", "64")), 64, 48, 256
 
 
 class Holder(torch.nn.Module):
@@ -33,6 +33,11 @@ with nnops.use_weights(m) as wc:
                 nnops._conv_raw(x, wf, C, 3, 1, False)
             elif what == "dgrad":
                 nnops._conv_dgrad(g, wd, C, 3, 1, (H, W))
+            elif what == "c64":          # 3x3 64 -> 64 @64x48 forward + statistics (k_conv3h, or k_igemm2 with PK_CONV3H=0)
+                if "x64" not in globals():
+                    x64 = torch.randn(B, H, W, 64, device=DEV).to(BF)
+                    w64 = torch.randn(64, 9, 64, device=DEV).to(BF)
+                nnops._conv_raw(x64, w64, 64, 3, 1, True)
             elif what == "wgrad":
                 nnops._wgrad(x, g, C, C, 3, 1, (B, H, W, H, W))
         torch.cuda.synchronize()

@@ -149,6 +149,48 @@ def test_conv8p_small_and_ragged_shapes(N, B, H, W, Cin, Cout, monkeypatch):
             assert err(C(dx), C(dx3)) < 8e-3
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 9, 7, 32, 32), (3, 11, 13, 64, 64), (1, 5, 5, 64, 32), (2, 24, 18, 32, 64), (4, 64, 48, 64, 64),
+                                            (2, 96, 72, 32, 32), (1, 40, 100, 64, 64), (5, 7, 30, 64, 64), (70, 3, 3, 32, 32)])
+def test_conv3h_halo_kernel_shapes(N, B, H, W, Cin, Cout, monkeypatch):
+    """k_conv3h (3x3 stride-1, 32 / 64 channels: padded-position K loop, input tile + halo once in LDS, weights in registers, persistent
+    workgroups) forced onto small and odd shapes: images narrower / shorter than a tile, tiles that span several samples, a 100-pixel-wide
+    map (11 DMA pieces per wave), every channel combination; forward with BatchNorm statistics, data gradient with and without the skip
+    addend, against fp32 PyTorch and against k_igemm2 on the same operands, bit-identical run to run."""
+    from infantposeestimation_gaussianbias_amd._lib import lib
+    monkeypatch.setenv("PK_CONV3H_MIN_TILES", "1")
+    conv = torch.nn.Conv2d(Cin, Cout, 3, 1, 1, bias=False)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight * 3))
+    x = rnd(B, Cin, H, W, seed=21)
+    xr = x.clone().requires_grad_(True)
+    ref = F.conv2d(xr, conv.weight, None, 1, 1)
+    gy = rnd(*ref.shape, seed=22)
+    ref.backward(gy)
+    import copy
+    m = Holder(c=copy.deepcopy(conv)).to(DEV)
+    with N.use_weights(m) as wc:
+        wf, wd = wc.fwd[id(m.c.weight)], wc.dgrad[id(m.c.weight)]
+        xd = nhwc(x)
+        ntiles, cus = (B * (H + 2) * (W + 2) + 127) // 128, torch.cuda.get_device_properties(0).multi_processor_count
+        assert lib.pk_conv_stats_rows(B, H, W, Cin, Cout, 3, 1, H, W) == 2 * min(ntiles, 2 * cus)      # the halo kernel is taken: one row per (workgroup, position half)
+        raw, part = N._conv_raw(xd, wf, Cout, 3, 1, True)
+        assert err(nchw(raw), ref.detach()) < 8e-3                                   # bf16 store
+        st = C(part).sum(0)
+        assert err(st[0], ref.detach().sum((0, 2, 3))) < FP32_TOL                    # statistics of the interior positions, from the fp32 accumulators
+        assert err(st[1], (ref.detach() ** 2).sum((0, 2, 3))) < FP32_TOL
+        raw2, part2 = N._conv_raw(xd, wf, Cout, 3, 1, True)
+        assert torch.equal(raw, raw2) and torch.equal(part, part2)
+        dx = N._conv_dgrad(nhwc(gy), wd, Cin, 3, 1, (H, W))
+        assert err(nchw(dx), xr.grad) < 8e-3
+        add = rnd(B, Cin, H, W, seed=23)
+        dxa = N._conv_dgrad(nhwc(gy), wd, Cin, 3, 1, (H, W), nhwc(add))
+        assert err(nchw(dxa), xr.grad + add) < 8e-3
+        monkeypatch.setenv("PK_CONV3H", "0")                                         # the same launches on k_igemm2
+        assert lib.pk_conv_stats_rows(B, H, W, Cin, Cout, 3, 1, H, W) == lib.pk_conv_stats_tiles(B * H * W)
+        raw3, _ = N._conv_raw(xd, wf, Cout, 3, 1, True)
+        assert err(C(raw), C(raw3)) < 8e-3 and float((C(raw) != C(raw3)).float().mean()) < 0.02
+
+
 def test_stem_conv_padded_input_and_head_out(N):
     """3-channel NCHW fp32 input -> NHWC bf16 padded to 8 channels -> 3x3 s2 conv; 1x1 head conv with bias/softplus to NCHW fp32."""
     conv = torch.nn.Conv2d(3, 64, 3, 2, 1, bias=False)

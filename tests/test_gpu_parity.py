@@ -1107,7 +1107,9 @@ def test_cfg1_trajectory_vs_bf16_aware_oracle(golden):
     dist = np.abs(np.array(got) - want) / want
     print("cfg1 trajectory HIP / oracle / oracle'", got, want, want2, "relative distance", dist, "self", floor)
     assert dist[0] < 5e-3                                   # first loss: forward only
-    assert np.all(dist <= 2 * floor + 1.5e-2), (dist, floor)
+    # the oracle's self-distance is ONE draw per step (measured 0.3 % / 1.0 % / 0.25 % on one box, 0.3 / 0.4 / 1.1 on another): the noise
+    # scale of the later steps is the largest of the three, not the draw of that step
+    assert np.all(dist <= 2 * floor.max() + 1.5e-2), (dist, floor)
 
 
 def test_head_output_epilogue_meets_north_star_1e3(N=None):

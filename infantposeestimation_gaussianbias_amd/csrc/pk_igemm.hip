@@ -48,6 +48,7 @@ struct IgemmArgs {
     int xcd_remap;            // set by igemm_launch (PK_IGEMM_XCD=0 disables the XCD-contiguous tile order)
     int vec8;                 // set by igemm_launch: row-major pointers 16-byte aligned and ldo % 8 == 0 -> 16-byte epilogue I/O
     int chunk_major;          // set by igemm_launch: K order = all taps of one channel chunk back to back (N <= 32 tiles of deep 3x3 convs)
+    int dil_group;            // set by igemm_launch (stride-2 data gradients): output pixels enumerated parity class by parity class
 };
 
 // ================================================================================================ main kernel (v2)
@@ -63,6 +64,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 template <int BK>
 __device__ __forceinline__ int swz(int row) { return BK == 64 ? ((row >> 1) & 7) : (((row >> 3) & 1) << 1); }
+// floor(q / d) for 0 <= q < 2^24 (d >= 1): float estimate + one correction, ~8 VALU (a 32-bit integer division by a run-time divisor
+// compiles to ~35; the pixel decompositions of the output-bound conv launches spent more issue slots on them than on MFMAs)
+__device__ __forceinline__ int fast_div24(int q, int d, float inv) {
+    int r = (int)((float)q * inv);
+    const int rem = q - r * d;
+    r += rem >= d ? 1 : (rem < 0 ? -1 : 0);
+    return r;
+}
 
 // Epilogue of ONE output row segment: this lane owns output row `orow` (pixel / token) and the 8 consecutive columns
 // n..n+7, handed over as two float4 read back from the LDS staging tile.  The accumulators are staged through LDS so
@@ -167,7 +176,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     IgemmArgs p = p_in;
     if (LEAN) {                      // LEAN = 2 keeps the GELU epilogues (fc1: GELU + saved pre-activation; fc2 data gradient: x gelu'(z))
         p.stats = nullptr;
-        p.out_mode = 0; p.T = 1; p.Ho = 0; p.Wo = 0; p.dilated = 0; p.vec8 = 1; p.chunk_major = 0;
+        p.out_mode = 0; p.T = 1; p.Ho = 0; p.Wo = 0; p.dilated = 0; p.vec8 = 1; p.chunk_major = 0; p.dil_group = 0;
         if (LEAN == 1) { p.preact = nullptr; p.gelu_of = nullptr; p.act = 0; }
         else if (p.act != 1) p.act = 0;
     }
@@ -217,6 +226,35 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
     const auto rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.w), 0, 0x7ffffff0, 0x00020000);
 
+    // Stride-2 data gradient (dilated gather): only the taps whose parity matches the output pixel's contribute -- 1, 2, 2 or 4 of the 9,
+    // by parity class (oy & 1, ox & 1).  With p.dil_group the GEMM rows enumerate the output pixels class by class (class-major, then
+    // sample, then row, then column of the class), so that a tile of BM rows lies in ONE class (except where two classes meet) and the
+    // K loop runs over that class's taps only: 2.25 K-steps per channel chunk on average instead of 9 (the other 6.75 multiplied zeros).
+    const bool grouped = !linear && p.dilated && p.dil_group;
+    const int gny0 = (p.Ho + 1) >> 1, gny1 = p.Ho >> 1, gnx0 = (p.Wo + 1) >> 1, gnx1 = p.Wo >> 1, gB = grouped ? p.M / (p.Ho * p.Wo) : 0;
+    const int gs1 = gB * gny0 * gnx0, gs2 = gs1 + gB * gny0 * gnx1, gs3 = gs2 + gB * gny1 * gnx0;      // first row of classes (0,1), (1,0), (1,1)
+    auto group_class = [&](int m) { return (m >= gs1 ? 1 : 0) + (m >= gs2 ? 1 : 0) + (m >= gs3 ? 1 : 0); };
+    const bool small_m24 = p.M < (1 << 24);          // exact range of fast_div24
+    auto idiv = [&](int q, int d) { return small_m24 ? fast_div24(q, d, 1.f / (float)d) : q / d; };
+    auto group_pixel = [&](int m, int& b, int& oy, int& ox) {
+        const int c = group_class(m), cy = c >> 1, cx = c & 1;
+        const int ny = cy ? gny1 : gny0, nx = cx ? gnx1 : gnx0;
+        const int r = m - (c == 0 ? 0 : (c == 1 ? gs1 : (c == 2 ? gs2 : gs3)));
+        b = idiv(r, ny * nx);
+        const int r2 = r - b * ny * nx, y = idiv(r2, nx);
+        oy = 2 * y + cy;
+        ox = 2 * (r2 - y * nx) + cx;
+    };
+    unsigned tapmask = 0x1ffu;          // taps this tile walks (bit kh * 3 + kw)
+    if (grouped) {
+        const int c0 = group_class(m0), c1 = group_class(min(m0 + BM, p.M) - 1);
+        if (c0 == c1) {                 // input index = (oy + kh - 1) / 2 must be whole: kh = 1 for even oy, kh in {0, 2} for odd oy
+            const unsigned rows = (c0 >> 1) ? 0x5u : 0x2u, cols = (c0 & 1) ? 0x5u : 0x2u;
+            tapmask = 0;
+            for (int kh = 0; kh < 3; ++kh)
+                if (rows >> kh & 1) tapmask |= cols << (3 * kh);
+        }
+    }
     // ---- fixed per-thread row descriptors
     int a_base[A_PT], a_iy[A_PT], a_ix[A_PT];
     bool a_ok[A_PT];
@@ -231,7 +269,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
                 a_ok[i] = src >= 0;
                 a_base[i] = src * p.Cin;
             } else {
-                const int hw = p.Ho * p.Wo, b = m / hw, r = m - b * hw, oy = r / p.Wo, ox = r - oy * p.Wo;
+                int b, oy, ox;
+                if (grouped) {
+                    group_pixel(m, b, oy, ox);
+                } else {
+                    const int hw = p.Ho * p.Wo;
+                    b = idiv(m, hw);
+                    const int r = m - b * hw;
+                    oy = idiv(r, p.Wo);
+                    ox = r - oy * p.Wo;
+                }
                 a_iy[i] = oy * p.stride - p.pad;
                 a_ix[i] = ox * p.stride - p.pad;
                 a_base[i] = b * p.Hs * p.Ws * p.Cin;
@@ -245,7 +292,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         b_off[i] = (q < BN * CH && n < p.N) ? (unsigned)((n * p.T * p.Cin + kcg * 8) * 2) : OOB_OFF;
     }
     const int kchunks = (p.Cin + BK - 1) / BK;
-    const int nk = p.T * kchunks;
+    const int nk = (grouped ? __builtin_popcount(tapmask) : p.T) * kchunks;
+    auto next_tap = [&](int t) {          // the next tap after t that this tile walks
+        ++t;
+        if (grouped)
+            while (t < 9 && !(tapmask >> t & 1)) ++t;
+        return t;
+    };
+    const int t_first = grouped ? next_tap(-1) : 0;
 
     unsigned a_voff[A_PT];           // byte offset of (row, current tap, channel kc*8), or OOB
     auto set_tap = [&](int t) {
@@ -319,7 +373,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int t_next = 0, c_next = 0;           // (tap, chunk) of the tile being loaded
+    int t_next = t_first, c_next = 0;     // (tap, chunk) of the tile being loaded
     // (Measured and dropped: chunk-major order -- all nine taps of one channel chunk back to back, so that the shifted re-reads of the
     // same pixels stay in L2 instead of cycling ~11 MB per XCD between two taps (PMC: the head conv fetches 4.1x its input).  The row
     // offsets must then be recomputed every step: head conv forward 335 -> 400 us, dgrad 290 -> 360 us; only N = 32 tiles gained.)
@@ -337,7 +391,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         c_next += BK;
         if (c_next >= p.Cin) {
             c_next = 0;
-            ++t_next;
+            t_next = next_tap(t_next);
             set_tap(t_next);
         }
     };
@@ -403,7 +457,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             }
         }
     };
-    set_tap(0);
+    set_tap(t_first);
     if constexpr (DMA) {
         static_assert(BM % RSTEP == 0 && BN % RSTEP == 0 && (RSTEP % 16) == 0, "lane-linear LDS-DMA layout: whole 1-KiB pieces per wave instruction");
         // (Tried on top: three LDS stages, loads two tiles ahead, one raw s_barrier per K-step with a counted `s_waitcnt vmcnt(6)`
@@ -411,7 +465,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         // per CU the other workgroup already covers the load latency; the remaining bound is LDS bandwidth.  The same pipeline on
         // a 256 x 256 tile with 128 x 128 per wave (a third less LDS traffic again, one wave per SIMD): correct, but 256 + 256
         // registers are not enough -- 796 bytes of scratch per lane, 417 / 316 us.)
-        dma_tiles(0, 0, 0);
+        dma_tiles(0, t_first, 0);
         __syncthreads();                              // drains vmcnt(0): tile 0 is in LDS
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
@@ -423,7 +477,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             __syncthreads();
         }
     } else {
-    load_tiles(ra, rb, 0, 0);
+    load_tiles(ra, rb, t_first, 0);
     store_tiles(ra, rb, 0);
     if constexpr (!DEEP) {
         __syncthreads();
@@ -550,8 +604,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
                 const int m = m0 + wm * TM + pass * BPP * 16 + ml;
                 int orow = (m < p.M) ? m : -1;
                 if (orow >= 0 && p.o_rowmap) orow = p.o_rowmap[m];
+                if (orow >= 0 && grouped) {                  // GEMM row of the parity-grouped enumeration -> output pixel row
+                    int gb, goy, gox;
+                    group_pixel(m, gb, goy, gox);
+                    orow = (gb * p.Ho + goy) * p.Wo + gox;
+                }
                 if (orow < 0) continue;
-                const float rs = p.res_scale ? p.res_scale[orow / p.rows_per_sample] : 1.f;
+                const float rs = p.res_scale ? p.res_scale[idiv(orow, p.rows_per_sample)] : 1.f;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc]);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc + 4]);
                 igemm_epilogue_row8(p, lo, hi, blo, bhi, orow, n, rs, hw_out);
@@ -1154,6 +1213,8 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     a.xcd_remap = xcd_on;
     static const int cm_on = getenv("PK_IGEMM_CHUNK_MAJOR") ? atoi(getenv("PK_IGEMM_CHUNK_MAJOR")) : 1;
     a.chunk_major = cm_on && a.T == 9 && a.N <= 32 && a.Cin >= 128 && (a.Cin % 64) == 0;
+    static const int dg_on = getenv("PK_IGEMM_DILGROUP") ? atoi(getenv("PK_IGEMM_DILGROUP")) : 1;
+    a.dil_group = dg_on && a.dilated && a.T == 9 && a.out_mode == 0 && !a.stats && !a.o_rowmap && !a.res_scale;
     if (conv3h_takes(a)) return conv3h_launch(a, st, who);
     if (conv8p_takes(a)) {
         hipLaunchKernelGGL(k_conv8p, dim3((unsigned)(((a.M + 255) / 256) * (a.N / 256))), dim3(512), 0, st, a);

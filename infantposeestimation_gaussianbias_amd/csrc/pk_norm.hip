@@ -3,6 +3,13 @@
 // packing.  All operate on NHWC bf16 rows of C channels, 8 channels (16 bytes) per lane.
 #include "pk_common.h"
 
+// floor(q / d) for 0 <= q < 2^24: float estimate + one correction (~8 VALU; a 32-bit division by a run-time divisor is ~35)
+__device__ __forceinline__ uint32_t fdiv24(uint32_t q, uint32_t d, float inv) {
+    int r = (int)((float)q * inv);
+    const int rem = (int)q - r * (int)d;
+    r += rem >= (int)d ? 1 : (rem < 0 ? -1 : 0);
+    return (uint32_t)r;
+}
 __device__ __forceinline__ void unpack8(const uint4& v, float* f) {
     const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -139,7 +146,8 @@ __global__ void __launch_bounds__(256) k_bn_act(const uint4* __restrict__ x, con
                                                 const float* __restrict__ shift, const uint4* __restrict__ res, uint4* __restrict__ y,
                                                 size_t chunks, int cchunks, int relu) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)((uint32_t)i % (uint32_t)cchunks) * 8;      // 32-bit: a size_t modulo is a ~60-instruction software division per chunk
+        // (32-bit: a size_t modulo is a ~60-instruction software division per chunk; a mask when the chunk count is a power of two)
+        const int c0 = (int)(((cchunks & (cchunks - 1)) == 0) ? ((uint32_t)i & (uint32_t)(cchunks - 1)) : ((uint32_t)i % (uint32_t)cchunks)) * 8;
         float v[8], r[8];
         unpack8(x[i], v);
         if (res) unpack8(res[i], r);
@@ -232,7 +240,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ 
                                                       uint4* __restrict__ dres, size_t chunks, int cchunks, int relu) {
     const int C = cchunks * 8;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
-        const int c0 = (int)((uint32_t)i % (uint32_t)cchunks) * 8;      // 32-bit: a size_t modulo is a ~60-instruction software division per chunk
+        // (32-bit: a size_t modulo is a ~60-instruction software division per chunk; a mask when the chunk count is a power of two)
+        const int c0 = (int)(((cchunks & (cchunks - 1)) == 0) ? ((uint32_t)i & (uint32_t)(cchunks - 1)) : ((uint32_t)i % (uint32_t)cchunks)) * 8;
         float g[8], xr[8], ya[8], o[8];
         unpack8(dy[i], g);
         unpack8(raw[i], xr);
@@ -585,13 +594,16 @@ __device__ __forceinline__ void bil_taps(int o, int n_in, int n_out, int& i0, in
 __global__ void __launch_bounds__(256) k_fuse_sum(FuseArgs a) {
     const int cchunks = a.C / 8;
     const size_t chunks = (size_t)a.B * a.H * a.W * cchunks;
+    const float inv_c = 1.f / (float)cchunks, inv_w = 1.f / (float)a.W, inv_h = 1.f / (float)a.H;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
         // (32-bit index arithmetic: five size_t divisions were ~300 VALU instructions per 16-byte output chunk)
-        const uint32_t i32 = (uint32_t)i, pix0 = i32 / (uint32_t)cchunks;
+        const uint32_t i32 = (uint32_t)i;
+        const bool f24 = chunks < (1u << 24);
+        const uint32_t pix0 = f24 ? fdiv24(i32, cchunks, inv_c) : i32 / (uint32_t)cchunks;
         const int cc = (int)(i32 - pix0 * (uint32_t)cchunks);
-        const uint32_t pix1 = pix0 / (uint32_t)a.W;
+        const uint32_t pix1 = f24 ? fdiv24(pix0, a.W, inv_w) : pix0 / (uint32_t)a.W;
         const int x = (int)(pix0 - pix1 * (uint32_t)a.W);
-        const int b = (int)(pix1 / (uint32_t)a.H), y = (int)(pix1 - (uint32_t)b * (uint32_t)a.H);
+        const int b = (int)(f24 ? fdiv24(pix1, a.H, inv_h) : pix1 / (uint32_t)a.H), y = (int)(pix1 - (uint32_t)b * (uint32_t)a.H);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         for (int k = 0; k < a.n; ++k) {
             const FuseIn& in = a.in[k];
@@ -656,17 +668,23 @@ __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict
     for (size_t it = 0; it < n_iter; ++it, i += groups_per_grid) {
         const bool on = i < chunks;
         const size_t ii = on ? i : 0;
-        const uint32_t i32 = (uint32_t)ii, pix0 = i32 / (uint32_t)cchunks;
+        const uint32_t i32 = (uint32_t)ii;
+        const bool f24 = chunks < (1u << 24);
+        const uint32_t pix0 = f24 ? fdiv24(i32, cchunks, 1.f / (float)cchunks) : i32 / (uint32_t)cchunks;
         const int cc = (int)(i32 - pix0 * (uint32_t)cchunks);
-        const uint32_t pix1 = pix0 / (uint32_t)Ws;
+        const uint32_t pix1 = f24 ? fdiv24(pix0, Ws, 1.f / (float)Ws) : pix0 / (uint32_t)Ws;
         const int xs = (int)(pix0 - pix1 * (uint32_t)Ws);
-        const int b = (int)(pix1 / (uint32_t)Hs), ys = (int)(pix1 - (uint32_t)b * (uint32_t)Hs);
+        const int b = (int)(f24 ? fdiv24(pix1, Hs, 1.f / (float)Hs) : pix1 / (uint32_t)Hs), ys = (int)(pix1 - (uint32_t)b * (uint32_t)Hs);
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         // support of source pixel ys: outputs whose source coordinate (oy + .5) * Hs/H - .5 lies in (ys-1, ys+1), i.e.
         // oy in ((ys-.5)*H/Hs - .5, (ys+1.5)*H/Hs - .5); H/Hs <= ry, one extra row each side covers non-integer ratios.
         // (The border clamps only move outputs that are already inside this range.)
-        const int oy_lo = max(0, (ys - 1) * ry - 1), oy_hi = min(H, (ys + 2) * ry + 1);
-        const int ox_lo = max(0, (xs - 1) * rx - 1), ox_hi = min(W, (xs + 2) * rx + 1);
+        // For an exact even ratio r the support is EXACTLY the 2r outputs [ys r - r/2, ys r + 3r/2): the generic window above scans
+        // 3r + 2 candidates per axis and computes the taps of each (r = 2: 64 candidates for 16 contributors -- the kernel was bound by
+        // that arithmetic, ~19 us for a 6 MB gradient).
+        const bool ey = (H == Hs * ry) && !(ry & 1), ex = (W == Ws * rx) && !(rx & 1);
+        const int oy_lo = ey ? max(0, ys * ry - ry / 2) : max(0, (ys - 1) * ry - 1), oy_hi = ey ? min(H, ys * ry + 3 * ry / 2) : min(H, (ys + 2) * ry + 1);
+        const int ox_lo = ex ? max(0, xs * rx - rx / 2) : max(0, (xs - 1) * rx - 1), ox_hi = ex ? min(W, xs * rx + 3 * rx / 2) : min(W, (xs + 2) * rx + 1);
         if (on)
             for (int oy = oy_lo + sub; oy < oy_hi; oy += SPLIT) {
                 int y0, y1;

@@ -204,6 +204,11 @@ int pk_bn_finalize(const float* stats_partial, int tiles, int C, int count, cons
                    float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
 int pk_bn_act(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
               int relu, void* stream);                       /* y = relu?(x*scale + shift (+ residual)) */
+/* Train-mode BatchNorm forward from the conv epilogue's partial statistics (nn.BatchNorm2d.forward in models/hrnet.py:24-52,
+ * models/hrformer.py:309-344): pk_bn_finalize + pk_bn_act, as ONE launch for small tensors (tiles <= 128).  scale / shift: [C] workspaces. */
+int pk_bn_train_fwd(const void* raw, const float* stats_partial, int tiles, int C, int64_t rows, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps, const void* residual,
+                    void* y, float* save_mean, float* save_rstd, float* scale, float* shift, int relu, void* stream);
 int pk_bn_bwd_blocks(int64_t rows);                          /* partial needs blocks*2*C floats */
 /* pk_bn_bwd `relu`: bit 0 = the forward applied ReLU (mask from y_act); bit 1 = eval-mode BatchNorm (save_mean / save_rstd hold the
  * running statistics, which are constants: dx = gamma * rstd * g, no batch-mean terms; dgamma / dbeta as in training).           */

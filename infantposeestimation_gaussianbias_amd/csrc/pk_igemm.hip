@@ -1212,7 +1212,7 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     static const int xcd_on = getenv("PK_IGEMM_XCD") ? atoi(getenv("PK_IGEMM_XCD")) : 1;
     a.xcd_remap = xcd_on;
     static const int cm_on = getenv("PK_IGEMM_CHUNK_MAJOR") ? atoi(getenv("PK_IGEMM_CHUNK_MAJOR")) : 1;
-    a.chunk_major = cm_on && a.T == 9 && a.N <= 32 && a.Cin >= 128 && (a.Cin % 64) == 0;
+    a.chunk_major = cm_on && a.T == 9 && a.N <= 32 && a.Cin >= 128 && (a.Cin % 64) == 0 && !a.dilated;      // (the dilated walk has its own tap list)
     static const int dg_on = getenv("PK_IGEMM_DILGROUP") ? atoi(getenv("PK_IGEMM_DILGROUP")) : 1;
     a.dil_group = dg_on && a.dilated && a.T == 9 && a.out_mode == 0 && !a.stats && !a.o_rowmap && !a.res_scale;
     if (conv3h_takes(a)) return conv3h_launch(a, st, who);

@@ -172,6 +172,109 @@ extern "C" int pk_bn_act(const void* x, const float* scale, const float* shift, 
     return pk_launch_status("pk_bn_act");
 }
 
+// Small tensors (<= BNS_MAX_TILES statistics rows, i.e. the low-resolution branches and their exchange units): finalize + apply in ONE
+// launch.  Each workgroup owns 32 channels x a block of rows and first reduces the partial statistics of ITS 32 channels itself (8 row
+// lanes per channel, fixed order, double: every workgroup computes bit-identical scale / shift), row block 0 also writes save_mean /
+// save_rstd and the running statistics.  One launch (~7 us of fixed cost on a latency-bound chain) less per layer.
+#define BNS_MAX_TILES 128
+#define BNS_CG 32
+__global__ void __launch_bounds__(256) k_bn_act_fin(const uint4* __restrict__ x, const float* __restrict__ part, int tiles, int C, float count,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                    float* __restrict__ run_var, long long* __restrict__ nbt, float momentum, float eps,
+                                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, const uint4* __restrict__ res,
+                                                    uint4* __restrict__ y, int rows, int rows_per_block, int relu) {
+    __shared__ double shs[8][BNS_CG], shq[8][BNS_CG];
+    __shared__ float s_scale[BNS_CG], s_shift[BNS_CG];
+    const int cg = blockIdx.x, rb = blockIdx.y, c0 = cg * BNS_CG;
+    {
+        const int cl = threadIdx.x & (BNS_CG - 1), pl = threadIdx.x >> 5, c = c0 + cl;
+        double sm = 0.0, sq = 0.0;
+        if (c < C)
+            for (int t = pl; t < tiles; t += 8) {
+                sm += (double)part[(size_t)t * 2 * C + c];
+                sq += (double)part[(size_t)t * 2 * C + C + c];
+            }
+        shs[pl][cl] = sm;
+        shq[pl][cl] = sq;
+    }
+    __syncthreads();
+    if (threadIdx.x < BNS_CG && c0 + threadIdx.x < C) {
+        const int cl = threadIdx.x, c = c0 + cl;
+        double sm = 0.0, sq = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            sm += shs[k][cl];
+            sq += shq[k][cl];
+        }
+        const double mean = sm / count;
+        double var = sq / count - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+        const float g = gamma[c];
+        s_scale[cl] = g * rstd;
+        s_shift[cl] = beta[c] - (float)mean * g * rstd;
+        if (rb == 0) {
+            mean_out[c] = (float)mean;
+            rstd_out[c] = rstd;
+            if (run_mean) {
+                const double unbiased = count > 1.f ? var * (double)count / ((double)count - 1.0) : var;
+                run_mean[c] = (1.f - momentum) * run_mean[c] + momentum * (float)mean;
+                run_var[c] = (1.f - momentum) * run_var[c] + momentum * (float)unbiased;
+            }
+            if (cg == 0 && cl == 0 && nbt) nbt[0] += 1;
+        }
+    }
+    __syncthreads();
+    const int cchunks = C / 8, ch = cg * (BNS_CG / 8) + (threadIdx.x & 3);
+    if (ch >= cchunks) return;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        sc[j] = s_scale[(threadIdx.x & 3) * 8 + j];
+        sh[j] = s_shift[(threadIdx.x & 3) * 8 + j];
+    }
+    const int r1 = min(rows, (rb + 1) * rows_per_block);
+    for (int r = rb * rows_per_block + (threadIdx.x >> 2); r < r1; r += 64) {
+        const size_t i = (size_t)r * cchunks + ch;
+        float v[8], rr[8];
+        unpack8(x[i], v);
+        if (res) unpack8(res[i], rr);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float t = v[j] * sc[j] + sh[j];
+            if (res) t += rr[j];
+            v[j] = relu ? fmaxf(t, 0.f) : t;
+        }
+        y[i] = pack8(v);
+    }
+}
+// Train-mode BatchNorm forward from the conv epilogue's partial statistics: finalize + apply.  One fused launch for small tensors, the
+// two kernels above otherwise.  `scale` / `shift`: [C] workspaces of the two-launch path.
+extern "C" int pk_bn_train_fwd(const void* raw, const float* stats_partial, int tiles, int C, int64_t rows, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
+                               float eps, const void* residual, void* y, float* save_mean, float* save_rstd, float* scale, float* shift,
+                               int relu, void* stream) {
+    PK_REQUIRE(raw && stats_partial && gamma && beta && y && save_mean && save_rstd && scale && shift, "pk_bn_train_fwd: null pointer");
+    PK_REQUIRE(tiles > 0 && C > 0 && (C & 7) == 0 && rows > 0, "pk_bn_train_fwd: bad sizes");
+    static const int fused_on = getenv("PK_BN_FUSED") ? atoi(getenv("PK_BN_FUSED")) : 1;
+    if (fused_on && tiles <= BNS_MAX_TILES && rows <= 32768) {
+        const int ncg = (C + BNS_CG - 1) / BNS_CG;
+        int nrb = (int)((rows + 127) / 128);                       // >= 128 rows per workgroup, ~256 workgroups in all
+        const int want = (256 + ncg - 1) / ncg;
+        if (nrb > want) nrb = want;
+        if (nrb < 1) nrb = 1;
+        const int rpb = (int)((rows + nrb - 1) / nrb);
+        hipLaunchKernelGGL(k_bn_act_fin, dim3(ncg, nrb), dim3(256), 0, (hipStream_t)stream, (const uint4*)raw, stats_partial, tiles, C, (float)rows,
+                           gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, save_mean, save_rstd,
+                           (const uint4*)residual, (uint4*)y, (int)rows, rpb, relu);
+        return pk_launch_status("pk_bn_train_fwd");
+    }
+    int rc = pk_bn_finalize(stats_partial, tiles, C, (int)rows, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
+                            shift, save_mean, save_rstd, stream);
+    if (rc) return rc;
+    return pk_bn_act(raw, scale, shift, residual, y, rows, C, relu, stream);
+}
+
 // Backward, pass 1: per-block partial sums over rows of g and g*xhat, g = dy * (y > 0 if relu).
 // (Measured and dropped: recomputing the ReLU mask from `raw` (scale/shift of the forward) to skip the read of `y` in both passes
 // made the step SLOWER, 21.97 -> 25.4 ms even with the path disabled at run time: the extra per-channel state costs these
@@ -258,11 +361,86 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ 
         if (dres) dres[i] = pack8(g);
     }
 }
+static inline bool bn_bwd_small(int64_t rows) {
+    static const int fused_on = getenv("PK_BN_FUSED") ? atoi(getenv("PK_BN_FUSED")) : 1;
+    return fused_on && rows <= 32768;
+}
 extern "C" int pk_bn_bwd_blocks(int64_t rows) {
     // >= 32 rows per block, up to 1024 blocks: the low-resolution branches (3 072 .. 12 288 rows) still get hundreds of
-    // workgroups (rows/256 left them with 12 .. 48 and a 55 us kernel for 3 MB of data)
+    // workgroups (rows/256 left them with 12 .. 48 and a 55 us kernel for 3 MB of data).  Small tensors: at most 64 blocks, because
+    // every workgroup of the fused apply kernel re-reduces the partial sums of its 32 channels itself (64 x 2 x 32 floats = 16 KB).
     int64_t nb = (rows + 31) / 32;
+    if (bn_bwd_small(rows) && nb > 64) nb = 64;
     return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
+}
+// Small tensors: pass 2 with the partial-sum reduction folded in (see k_bn_act_fin): each workgroup owns 32 channels x a block of rows,
+// reduces partial[nb][2][C] for its channels (8 lanes, fixed order, double), row block 0 writes dbeta / dgamma; then dx (and dres).
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_fin(const uint4* __restrict__ dy, const uint4* __restrict__ yact, const uint4* __restrict__ raw,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ part, int nb,
+                                                          float inv_count, float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                          uint4* __restrict__ dx, uint4* __restrict__ dres, int rows, int rows_per_block, int C,
+                                                          int relu) {
+    __shared__ double sh1[8][BNS_CG], sh2[8][BNS_CG];
+    __shared__ float s_1[BNS_CG], s_2[BNS_CG];
+    const int cg = blockIdx.x, rb = blockIdx.y, c0 = cg * BNS_CG;
+    {
+        const int cl = threadIdx.x & (BNS_CG - 1), pl = threadIdx.x >> 5, c = c0 + cl;
+        double a = 0.0, b = 0.0;
+        if (c < C)
+            for (int t = pl; t < nb; t += 8) {
+                a += (double)part[(size_t)t * 2 * C + c];
+                b += (double)part[(size_t)t * 2 * C + C + c];
+            }
+        sh1[pl][cl] = a;
+        sh2[pl][cl] = b;
+    }
+    __syncthreads();
+    if (threadIdx.x < BNS_CG && c0 + threadIdx.x < C) {
+        const int cl = threadIdx.x;
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a += sh1[k][cl];
+            b += sh2[k][cl];
+        }
+        s_1[cl] = (float)a;
+        s_2[cl] = (float)b;
+        if (rb == 0) {
+            dbeta[c0 + cl] = (float)a;
+            dgamma[c0 + cl] = (float)b;
+        }
+    }
+    __syncthreads();
+    const int cchunks = C / 8, ch = cg * (BNS_CG / 8) + (threadIdx.x & 3);
+    if (ch >= cchunks) return;
+    float mu[8], rs[8], gm[8], t1[8], t2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = ch * 8 + j;
+        mu[j] = mean[c];
+        rs[j] = rstd[c];
+        gm[j] = gamma[c] * rs[j];
+        t1[j] = s_1[(threadIdx.x & 3) * 8 + j] * inv_count;
+        t2[j] = s_2[(threadIdx.x & 3) * 8 + j] * inv_count;
+    }
+    const int r1 = min(rows, (rb + 1) * rows_per_block);
+    for (int r = rb * rows_per_block + (threadIdx.x >> 2); r < r1; r += 64) {
+        const size_t i = (size_t)r * cchunks + ch;
+        float g[8], xr[8], ya[8], o[8];
+        unpack8(dy[i], g);
+        unpack8(raw[i], xr);
+        if (relu) unpack8(yact[i], ya);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float gg = (relu && !(ya[j] > 0.f)) ? 0.f : g[j];
+            g[j] = gg;
+            const float xh = (xr[j] - mu[j]) * rs[j];
+            o[j] = gm[j] * (gg - t1[j] - xh * t2[j]);
+        }
+        dx[i] = pack8(o);
+        if (dres) dres[i] = pack8(g);
+    }
 }
 extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* save_mean, const float* save_rstd,
                          const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
@@ -281,6 +459,18 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     const int rpb = (int)((rows + nb - 1) / nb);
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw, save_mean,
                        save_rstd, partial, rows, C, relu, rpb);
+    if (bn_bwd_small(rows)) {          // the reduction of the partial sums rides in the apply launch
+        const int ncg = (C + BNS_CG - 1) / BNS_CG;
+        int nrb = (int)((rows + 127) / 128);
+        const int want = (256 + ncg - 1) / ncg;
+        if (nrb > want) nrb = want;
+        if (nrb < 1) nrb = 1;
+        const int rpb2 = (int)((rows + nrb - 1) / nrb);
+        hipLaunchKernelGGL(k_bn_bwd_apply_fin, dim3(ncg, nrb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw, save_mean,
+                           save_rstd, gamma, partial, nb, eval_mode ? 0.f : 1.f / (float)rows, dbeta, dgamma, (uint4*)dx, (uint4*)dresidual, (int)rows,
+                           rpb2, C, relu);
+        return pk_launch_status("pk_bn_bwd");
+    }
     // sums = [sum g | sum g*xhat] for the apply kernel; the same values go to dbeta / dgamma (possibly flat-gradient views)
     hipLaunchKernelGGL(k_sum_partials, SUM_PARTIALS_GRID(2 * C), dim3(16 * RED_LANES), 0, st, partial, nb, 2 * C, 2 * C, sums, 1.f, 0, dbeta, dgamma, C);
     size_t gb = (chunks + 255) / 256;

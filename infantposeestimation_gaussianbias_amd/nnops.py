@@ -428,10 +428,13 @@ class _ConvBnAct(torch.autograd.Function):
         raw, part = _conv_raw(x, wf, Cout, ksize, stride, training)
         scale, shift = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
         mean, rstd = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
+        y = _e(raw.shape, BF16, dev)
+        res = None if residual is None else residual.contiguous()
         if training:
             wc.bn_eval.pop(id(bn), None)        # the kernel below rewrites the running statistics in place (no version bump)
-            call("pk_bn_finalize", part, part.shape[0], Cout, M, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                 0.1, 1e-5, scale, shift, mean, rstd, stream_ptr())
+            # finalize + apply: one fused launch for small tensors, two kernels otherwise (the library decides)
+            call("pk_bn_train_fwd", raw, part, part.shape[0], Cout, M, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
+                 0.1, 1e-5, res, y, mean, rstd, scale, shift, 1 if relu else 0, stream_ptr())
         else:
             # eval: scale / shift are constants of the parameters -- computed once (4 small ATen launches) and kept until the weights or
             # the statistics change (was: 4 launches per BatchNorm layer and forward, 320 per HRFormer-base inference step)
@@ -446,9 +449,7 @@ class _ConvBnAct(torch.autograd.Function):
                 wc.bn_eval[id(bn)] = (key, scale, shift, mean, rstd)
             else:
                 _, scale, shift, mean, rstd = ent
-        y = _e(raw.shape, BF16, dev)
-        res = None if residual is None else residual.contiguous()
-        call("pk_bn_act", raw, scale, shift, res, y, M, Cout, 1 if relu else 0, stream_ptr())
+            call("pk_bn_act", raw, scale, shift, res, y, M, Cout, 1 if relu else 0, stream_ptr())
         ctx.save_for_backward(x, raw, y, mean, rstd, gamma, wd)
         ctx.meta = (stride, relu, training, residual is not None, Cin_real, ksize, (B, Hs, Ws, Ho, Wo))
         return y

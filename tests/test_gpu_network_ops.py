@@ -79,7 +79,11 @@ class Holder(torch.nn.Module):
                                                 # >= 256 pixel tiles of 256 rows with N % 256 == 0, Cin % 64 == 0, K >= 576: the 8-phase kernel
                                                 # k_conv8p (forward, and data gradient where Cout % 64 == 0 and Cin % 256 == 0): ragged last tile,
                                                 # 1 / 2 / 4 channel chunks per tap, two n-tiles, a deep 1x1
-                                                (3, 160, 143, 256, 256, 3, 1), (2, 192, 180, 64, 512, 3, 1), (2, 190, 181, 640, 256, 1, 1)])
+                                                (3, 160, 143, 256, 256, 3, 1), (2, 192, 180, 64, 512, 3, 1), (2, 190, 181, 640, 256, 1, 1),
+                                                # stride-2 data gradients large enough that whole 128-row tiles lie in ONE parity class (the K loop
+                                                # then walks that class's 1 / 2 / 2 / 4 taps only): even and odd map sizes, N <= 32 with a deep
+                                                # contraction (the shape that also qualifies for the chunk-major order of stride-1 convs)
+                                                (4, 32, 24, 32, 32, 3, 2), (4, 32, 24, 32, 128, 3, 2), (3, 33, 27, 64, 64, 3, 2), (2, 64, 48, 64, 256, 3, 2)])
 def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
     from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
     conv = torch.nn.Conv2d(Cin, Cout, k, s, k // 2, bias=False)

@@ -197,17 +197,29 @@ def roofline_table(model, B, trainer=None):
         sec = time_kernel(wgrad_slabs(u1, dq1, Mw1, 192, 64, 1, (B, 32, 24), a_map=amap1))
         E("k_wgrad4w<128,64>", f"qkv weight gradient, branch 1: {Mw1} window tokens x 192 x 64, gathered rows (slabs)", "hbm", sec,
           flops=2.0 * Mw1 * 192 * 64, bytes_=2.0 * (Mw1 * 192 + B * 32 * 24 * 64), trace="k_wgrad4w<128, 64>(WgradArgs)")
-        # 4. k_igemm2<128,64,4,1,64>: its largest shape = 3x3 conv 64->64 @64x48 (layer1 / transition convs), forward with BN statistics
+        # 4. k_conv3h<64,64> (halo kernel): 3x3 conv 64->64 @64x48 (layer1), forward with BN statistics; HBM-bound by arithmetic
         x64 = torch.randn(B, H, W, 64, device=dev).to(BF)
         w64 = torch.randn(64, 9, 64, device=dev).to(BF)
         sec = time_kernel(lambda: nnops._conv_raw(x64, w64, 64, 3, 1, True))
-        E("k_igemm2<128,64,4,1,64>", "conv3x3 64->64 @64x48 fwd + BN-stat epilogue", "mfma", sec, flops=2.0 * M * 64 * 9 * 64,
-          bytes_=2.0 * (2 * M * 64), trace="k_igemm2<128, 64, 4, 1, 64>(IgemmArgs)")
+        E("k_conv3h<64,64>", "conv3x3 64->64 @64x48 fwd + BN statistics (same kernel: data gradient)", "hbm", sec, flops=2.0 * M * 64 * 9 * 64,
+          bytes_=2.0 * (2 * M * 64), trace="k_conv3h<64, 64>(IgemmArgs, int)", single_shape=True)
+        # 4a. k_igemm2<128,64,4,1,32>: the most-launched GEMM tile of the step (token GEMMs and 1x1 convs with K <= 128); probe = 1x1 conv
+        #     64->256 @64x48 data gradient (N = 64, K = 256 goes to the BK = 64 tile; this is its forward twin N = 256, K = 64, no statistics)
+        w1 = torch.randn(256, 1, 64, device=dev).to(BF)
+        sec = time_kernel(lambda: nnops._conv_raw(x64, w1, 256, 1, 1, False))
+        E("k_igemm2<128,64,4,1,32>", "conv1x1 64->256 @64x48 (output-bound: 25 MB in, 100 MB out)", "hbm", sec, flops=2.0 * M * 256 * 64,
+          bytes_=2.0 * (M * 64 + M * 256), trace="k_igemm2<128, 64, 4, 1, 32, 0>(IgemmArgs)")
+        # 4c. stride-2 data gradient (parity-grouped tap walk): stem conv2 64->64 s2, dx at 128x96
+        g2 = torch.randn(B, H, W, 64, device=dev).to(BF)
+        wd2 = torch.randn(64, 9, 64, device=dev).to(BF)
+        sec = time_kernel(lambda: nnops._conv_dgrad(g2, wd2, 64, 3, 2, (128, 96)))
+        E("k_igemm2<128,64,4,1,64> (dilated)", "data gradient of conv3x3 s2 64->64: dx 128x96 from dy 64x48, 2.25 of 9 taps per pixel", "hbm", sec,
+          flops=2.0 * (4 * M) * 64 * 64 * 2.25, bytes_=2.0 * (M * 64 + 4 * M * 64), trace=None)
         # 4b. k_igemm2<128,32,4,1,64>: largest shape = 3x3 conv 256->32 @64x48 (transition1 branch 0 forward / data gradient of the head's 32->256 conv)
         w32 = torch.randn(32, 9, 256, device=dev).to(BF)
         sec = time_kernel(lambda: nnops._conv_raw(x, w32, 32, 3, 1, True))
         E("k_igemm2<128,32,4,1,64>", "conv3x3 256->32 @64x48 fwd + BN-stat epilogue", "mfma", sec, flops=2.0 * M * 32 * 9 * 256,
-          bytes_=2.0 * (M * 256 + M * 32), trace="k_igemm2<128, 32, 4, 1, 64>(IgemmArgs)")
+          bytes_=2.0 * (M * 256 + M * 32), trace="k_igemm2<128, 32, 4, 1, 64, 0>(IgemmArgs)")
         # 5./6. the fused block halves of branch 0 (C = 32): bytes = x in + y out (forward), x + dy in, dx out (backward)
         blk = model.backbone.stage2[0].branches[0][0]
         xb = torch.randn(B, H, W, 32, device=dev).to(BF)

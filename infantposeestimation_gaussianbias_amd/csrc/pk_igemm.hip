@@ -2436,7 +2436,9 @@ static int wgrad4_slices(int rows, int N, int Cin, int kind) {
     wgrad4_tile(N, Cin, kind, tn, tc);
     const int tiles = ((N + tn - 1) / tn) * (((kind == 3 ? 9 * Cin : Cin) + tc - 1) / tc);
     int s = ((kind == 2 ? t9 : t1) + tiles - 1) / tiles;
-    const int max_s = (rows + min_rows - 1) / min_rows;
+    static const int min_rows_w = getenv("PK_WGRAD4W_ROWS") ? atoi(getenv("PK_WGRAD4W_ROWS")) : min_rows;      // kind 4: window-gathered / row-scaled
+    const int mr = kind == 4 ? min_rows_w : min_rows;
+    const int max_s = (rows + mr - 1) / mr;
     if (s > max_s) s = max_s;
     return s < 1 ? 1 : s;
 }

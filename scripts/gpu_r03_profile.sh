@@ -27,9 +27,10 @@ k = dict(stp["kernels"])
 k.update(iso["kernels"])           # the isolated pass wins for the kernels it covers (one shape per kernel name)
 json.dump({"note": iso["note"], "sources": "isolated probes (scripts/prof_kernels.py isolated) over a whole eager step (… step)", "kernels": k},
           open("gpurun_out/r03_pmc_traffic.json", "w"), indent=1)
-for n in ("k_conv8p", "k_wgrad3", "k_igemm2<128, 64, 4, 1, 64>", "k_igemm2<128, 32, 4, 1, 64>", "k_reduce_many", "k_attn_bwd<32>", "k_mlp_fwd<32>"):
+for n in ("k_conv8p", "k_wgrad3", "k_conv3h<64, 64>", "k_igemm2<128, 32, 4, 1, 64, 0>", "k_reduce_many", "k_attn_bwd<32>", "k_mlp_fwd<32>"):
     print(n, k.get(n))
 PY
+bash scripts/gpu_pmc_sq.sh > gpurun_out/r03_sq.log 2>&1 || tail -3 gpurun_out/r03_sq.log
 # bench lines (the default line last: it is the one the roofline entries read profiles/ for)
 timeout -k 10 300 python bench.py --config hrnet_w32_384 --steps 30 --warmup 8 > gpurun_out/r03_bench_line_hrnet_w32_384.json 2> gpurun_out/r03_bench_w32.err || tail -3 gpurun_out/r03_bench_w32.err
 timeout -k 10 300 python bench.py --config hrformer_base_infer --steps 30 --warmup 5 > gpurun_out/r03_bench_line_hrformer_base_infer.json 2> gpurun_out/r03_bench_base.err || tail -3 gpurun_out/r03_bench_base.err

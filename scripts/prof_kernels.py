@@ -38,7 +38,7 @@ else:
     for _ in range(3):
         nnops._conv_raw(x256, w256, 256, 3, 1, True)                       # k_conv8p forward + statistics
         nnops._conv_dgrad(g256, wd256, 256, 3, 1, (H, W))                  # k_conv8p data gradient
-        nnops._conv_raw(x64, w64, 64, 3, 1, True)                          # k_igemm2<128,64,4,1,64>
+        nnops._conv_raw(x64, w64, 64, 3, 1, True)                          # k_conv3h<64,64>
         nnops._conv_raw(x256, w32, 32, 3, 1, True)                         # k_igemm2<128,32,4,1,64>
         S = lib.pk_wgrad_slices(M, 256, 256, 3, 1, H, W, 0)
         ws = torch.empty(S * 256 * (9 * 256 + 1), device=DEV)

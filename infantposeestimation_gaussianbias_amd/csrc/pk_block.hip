@@ -215,9 +215,7 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(MlpArgs p) {
                     for (int rt = 0; rt < RT; ++rt) h[rt][u] = MFMA(a, vf[rt][k], h[rt][u]);
                 }
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h[rt][u][r] = gelu_erf(h[rt][u][r]);
+                for (int rt = 0; rt < RT; ++rt) h[rt][u] = gelu_erf(h[rt][u]);
             }
             bf16x8 hf[RT];
 #pragma unroll
@@ -336,9 +334,7 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dx(MlpArgs p) {
                     }
                 }
 #pragma unroll
-                for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) dz[rt][u][r] = dh[rt][r] * gelu_grad(z[rt][r]);
+                for (int rt = 0; rt < RT; ++rt) dz[rt][u] = dh[rt] * gelu_grad(z[rt]);
             }
             bf16x8 dzf[RT];
 #pragma unroll
@@ -505,14 +501,9 @@ __global__ void __launch_bounds__(256) k_mlp_bwd_dw(MlpArgs p) {
                 }
 #pragma unroll
                 for (int rt = 0; rt < RT; ++rt) {
-                    f32x4 hh, dz;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        float gv, gd;                       // gelu and gelu' share the exponential and the erf polynomial
-                        gelu_both(z[rt][r], gv, gd);
-                        hh[r] = gv;
-                        dz[r] = dh[rt][r] * gd;
-                    }
+                    f32x4 hh, dz;                           // gelu and gelu' share the erf polynomial
+                    gelu_both(z[rt], hh, dz);
+                    dz *= dh[rt];
                     *reinterpret_cast<u32x2*>(tH + (16 * rt + i16) * PH + 16 * u + 4 * g) = pack4(hh);
                     *reinterpret_cast<u32x2*>(tD + (16 * rt + i16) * PH + 16 * u + 4 * g) = pack4(dz);
                 }

@@ -90,6 +90,14 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 //   gelu'(x) = Phi(x) + x exp(-x^2/2) / sqrt(2 pi),   Phi = x >= 0 ? 1 - hw : hw
 // 1 v_rcp + 1 v_exp + 11 (gelu) / 14 (gelu') plain VALU ops.  (libm erff is ~60 instructions with a divergent branch; the first
 // version of this code used __frcp_rn, which hipcc expands to a correctly rounded division: 10 instructions instead of one.)
+// (-DPK_GELU_POLY=1 selects the rcp/exp-free polynomial form further down: measured in the captured training step, same box,
+// alternating runs: 17.30 / 17.25 ms with it, 17.39 / 17.02 ms without -- the fused MLP kernels wait on memory and on MFMA results
+// (profiles/r03_pmc_sq_counters.json: VALU active 25-42 % of the wave cycles), they do not queue on the VALU; and its 4e-5 absolute
+// error is visible to the whole-model golden test.  Kept for reference, off.)
+#ifndef PK_GELU_POLY
+#define PK_GELU_POLY 0
+#endif
+#if !PK_GELU_POLY
 struct GeluTerms { float hw, e; };
 __device__ __forceinline__ GeluTerms gelu_terms(float x) {
     const float ax = fabsf(x);
@@ -116,6 +124,103 @@ __device__ __forceinline__ void gelu_both(float x, float& val, float& grad) {
     val = __fmaf_rn(-fabsf(x), g.hw, fmaxf(x, 0.f));
     grad = __fmaf_rn(x * 0.39894228040143267794f, g.e, gelu_cdf(x, g.hw));
 }
+typedef __attribute__((ext_vector_type(4))) float pk_f32x4;          // componentwise forms (A/B builds with -DPK_GELU_POLY=0)
+__device__ __forceinline__ pk_f32x4 gelu_erf(pk_f32x4 x) { return (pk_f32x4){gelu_erf(x[0]), gelu_erf(x[1]), gelu_erf(x[2]), gelu_erf(x[3])}; }
+__device__ __forceinline__ pk_f32x4 gelu_grad(pk_f32x4 x) { return (pk_f32x4){gelu_grad(x[0]), gelu_grad(x[1]), gelu_grad(x[2]), gelu_grad(x[3])}; }
+__device__ __forceinline__ void gelu_both(pk_f32x4 x, pk_f32x4& val, pk_f32x4& grad) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float a, b;
+        gelu_both(x[i], a, b);
+        val[i] = a;
+        grad[i] = b;
+    }
+}
+#else
+// Experiment (round 3): the rcp and the exp of that form are quarter-rate instructions (together as expensive as the eleven plain ones), and
+// none of it maps onto the packed fp32 pipe.  erf(x / sqrt 2) = xc P(xc^2), xc = clamp(x, -4.2, 4.2), P of degree 8 (minimax fit of
+// this file's author, scripts/fit_gelu_poly.py; |error| <= 1.5e-5 inside the interval, 2.7e-5 = 1 - erf(4.2 / sqrt 2) beyond it;
+// gelu: <= 4.4e-5 absolute, gelu': <= 1.1e-5 -- two orders of magnitude below the bf16 rounding of the tensors the results are
+// stored to): one v_med3 + multiplies and FMAs only, and in the 4-wide form (an MFMA accumulator tile) every multiply / FMA is a
+// v_pk_mul_f32 / v_pk_fma_f32 on two values: 7.5 issue slots per value instead of 19.  The scalar and the 4-wide form round
+// identically (same FMA chain per value).
+typedef __attribute__((ext_vector_type(4))) float pk_f32x4;
+#define PK_GELU_CLAMP 4.2f
+#define PK_GELU_C0 0.79781485f
+#define PK_GELU_C1 -0.13272066f
+#define PK_GELU_C2 0.019660205f
+#define PK_GELU_C3 -0.0022282742f
+#define PK_GELU_C4 0.0001891444f
+#define PK_GELU_C5 -1.1521039e-05f
+#define PK_GELU_C6 4.6870278e-07f
+#define PK_GELU_C7 -1.1265554e-08f
+#define PK_GELU_C8 1.1994644e-10f
+__device__ __forceinline__ float erf_rsqrt2(float x) {           // erf(x / sqrt 2)
+    const float xc = __builtin_amdgcn_fmed3f(x, -PK_GELU_CLAMP, PK_GELU_CLAMP);
+    const float s = xc * xc;
+    float q = __fmaf_rn(PK_GELU_C8, s, PK_GELU_C7);
+    q = __fmaf_rn(q, s, PK_GELU_C6);
+    q = __fmaf_rn(q, s, PK_GELU_C5);
+    q = __fmaf_rn(q, s, PK_GELU_C4);
+    q = __fmaf_rn(q, s, PK_GELU_C3);
+    q = __fmaf_rn(q, s, PK_GELU_C2);
+    q = __fmaf_rn(q, s, PK_GELU_C1);
+    q = __fmaf_rn(q, s, PK_GELU_C0);
+    return xc * q;
+}
+__device__ __forceinline__ pk_f32x4 erf_rsqrt2(pk_f32x4 x) {
+    pk_f32x4 xc;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) xc[i] = __builtin_amdgcn_fmed3f(x[i], -PK_GELU_CLAMP, PK_GELU_CLAMP);
+    const pk_f32x4 s = xc * xc;
+    pk_f32x4 q = __builtin_elementwise_fma((pk_f32x4)(PK_GELU_C8), s, (pk_f32x4)(PK_GELU_C7));
+    q = __builtin_elementwise_fma(q, s, (pk_f32x4)(PK_GELU_C6));
+    q = __builtin_elementwise_fma(q, s, (pk_f32x4)(PK_GELU_C5));
+    q = __builtin_elementwise_fma(q, s, (pk_f32x4)(PK_GELU_C4));
+    q = __builtin_elementwise_fma(q, s, (pk_f32x4)(PK_GELU_C3));
+    q = __builtin_elementwise_fma(q, s, (pk_f32x4)(PK_GELU_C2));
+    q = __builtin_elementwise_fma(q, s, (pk_f32x4)(PK_GELU_C1));
+    q = __builtin_elementwise_fma(q, s, (pk_f32x4)(PK_GELU_C0));
+    return xc * q;
+}
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float h = 0.5f * x;
+    return __fmaf_rn(h, erf_rsqrt2(x), h);
+}
+__device__ __forceinline__ pk_f32x4 gelu_erf(pk_f32x4 x) {
+    const pk_f32x4 h = x * 0.5f;
+    return __builtin_elementwise_fma(h, erf_rsqrt2(x), h);
+}
+// gelu'(x) = Phi(x) + x exp(-x^2 / 2) / sqrt(2 pi)
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.44269504088896340736f));
+    return __fmaf_rn(x * 0.39894228040143267794f, e, __fmaf_rn(0.5f, erf_rsqrt2(x), 0.5f));
+}
+__device__ __forceinline__ pk_f32x4 gelu_grad(pk_f32x4 x) {
+    const pk_f32x4 a = (x * x) * (-0.5f * 1.44269504088896340736f);
+    pk_f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a[i]);
+    const pk_f32x4 cdf = __builtin_elementwise_fma((pk_f32x4)(0.5f), erf_rsqrt2(x), (pk_f32x4)(0.5f));
+    return __builtin_elementwise_fma(x * 0.39894228040143267794f, e, cdf);
+}
+// value and derivative from one evaluation of the shared terms
+__device__ __forceinline__ void gelu_both(float x, float& val, float& grad) {
+    const float er = erf_rsqrt2(x), h = 0.5f * x;
+    const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.44269504088896340736f));
+    val = __fmaf_rn(h, er, h);
+    grad = __fmaf_rn(x * 0.39894228040143267794f, e, __fmaf_rn(0.5f, er, 0.5f));
+}
+__device__ __forceinline__ void gelu_both(pk_f32x4 x, pk_f32x4& val, pk_f32x4& grad) {
+    const pk_f32x4 er = erf_rsqrt2(x), h = x * 0.5f;
+    const pk_f32x4 a = (x * x) * (-0.5f * 1.44269504088896340736f);
+    pk_f32x4 e;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e[i] = __builtin_amdgcn_exp2f(a[i]);
+    val = __builtin_elementwise_fma(h, er, h);
+    grad = __builtin_elementwise_fma(x * 0.39894228040143267794f, e, __builtin_elementwise_fma((pk_f32x4)(0.5f), er, (pk_f32x4)(0.5f)));
+}
+#endif
 __device__ __forceinline__ float softplus_(float v) { return v > 20.f ? v : log1pf(__expf(v)); }
 
 // Sum over the 16 lanes of a DPP row (lanes 16 k .. 16 k + 15), result in every lane of the row: two quad permutes and two row

@@ -135,7 +135,9 @@ def join_side_streams(cur=None):
 # (Measured and removed: issuing the weight-gradient kernels on auxiliary streams -- they are off the data-gradient dependency
 # chain -- made the captured step SLOWER, 25.4 -> 31.0 ms for all of them and -1 % at best for the head's five large ones: their
 # >= 2 048-workgroup grids take CUs from the critical chain instead of filling its bubbles, and hipGraph maps parallel branches
-# onto 4 hardware queues (DEBUG_HIP_FORCE_GRAPH_QUEUES; more queues do not help).)
+# onto 4 hardware queues (DEBUG_HIP_FORCE_GRAPH_QUEUES; more queues do not help).  Round 3, again for the SERIAL phases only (stem, layer1,
+# transitions: one kernel in flight, the weight gradients of >= 100 000-row convs on one auxiliary stream joined by finalize_deferred):
+# 17.16 vs 17.21 ms over four alternating runs each -- inside the noise, not kept.)
 
 
 def _tensors(obj):

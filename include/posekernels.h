@@ -242,6 +242,13 @@ int pk_ln_mlp_dx_blocks(int M, int C);
 int pk_ln_mlp_dw_blocks(int M, int C);
 int pk_ln_mlp_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                   const float* b2, const float* row_scale, void* y, int M, int C, int rows_per_sample, float eps, void* stream);
+/* The same half for wide channels (C = 80 / 128 / 160 / 256 / 320; hrformer.py:262-293 with Mlp :38-64 at stage-3/4 widths and the
+ * 8-aligned twin of HRFormer-base :779-825), forward only: fc1 / fc2 weights streamed through LDS in hidden slices of 32.  `c_real` <= C:
+ * channels the LayerNorm statistics run over (the padded channels hold zeros).  w1 [hidden][C], w2 [C][hidden] bf16 row-major. */
+int pk_ln_mlp_wide_supported(int C, int hidden);
+int pk_ln_mlp_wide_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
+                       const float* b2, const float* row_scale, void* y, int M, int C, int c_real, int hidden, int rows_per_sample,
+                       float eps, void* stream);
 int pk_ln_mlp_bwd_dx(const void* dy, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
                      const void* w1_t, const void* w2_t, const float* row_scale, void* dx, float* ln_partial, int M, int C,
                      int rows_per_sample, float eps, void* stream);

@@ -237,6 +237,170 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(MlpArgs p) {
     }
 }
 
+// ================================================================================================ forward, wide channels
+// C = 80 ... 320 (branches 2-3 of HRFormer-small, the 8-aligned twin of HRFormer-base): W1 and W2 (8 C^2 bytes each) do not fit the
+// LDS any more, so the hidden dimension is walked in slices of 32 units and the 2 NK + NCT weight fragments of a slice (W1 rows of
+// the slice, W2 columns of the slice) are STREAMED: global (L2-resident) -> registers -> a two-slot LDS ring in fragment order, the
+// loads of slice s + 2 in flight while slice s is multiplied, one workgroup barrier per slice.  A workgroup is WAVES x 32 tokens
+// (every wave reads every fragment: 8 waves = 256 tokens per 16 C^2 bytes of L2 traffic); x is read once for the LayerNorm / fc1
+// operand and once more (L2 hit) for the residual, so the accumulators of fc2 (2 x NCT tiles) and the LayerNorm output (2 x NK
+// fragments) are all a wave has to hold.  Channels beyond C inside the last 32-wide K step (C = 80: NK = 3) are zero operands: the
+// loads of x, gamma, beta and of the weight columns are out of range there.  `c_real` < C (padded twins, models/padded.py): the
+// LayerNorm statistics run over the real channels -- the padded ones hold exact zeros, so the sums only need the divisor, and the
+// squared-deviation sum is corrected by (32 NK - c_real) mean^2.
+template <int NK, int NCT, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_mlp_fwd_w(MlpArgs p, int C, int c_real, int HD) {
+    constexpr int RT = 2, NF = 2 * NK + NCT, NLD = (NF + WAVES - 1) / WAVES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    u32x4* ring = reinterpret_cast<u32x4*>(smem_w);                      // [2][NF][64] fragments of the slice being multiplied / staged
+    float* sB1 = reinterpret_cast<float*>(smem_w + 2 * NF * 1024);       // [HD]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
+    const auto rw1 = MAKE_RSRC(p.w1), rw2 = MAKE_RSRC(p.w2);
+    // staging: fragment f = wave + WAVES j of a slice is fetched by this wave (lane l = the fragment's lane)
+    unsigned soff[NLD], sstep[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int f = wave + WAVES * j;
+        if (f < 2 * NK) {                    // W1 rows hid(2s + u, i), columns 32k + 8g ..
+            const int u = f / NK, k = f - u * NK, col = 32 * k + 8 * g;
+            soff[j] = col < C ? (unsigned)((hid(u, i16) * C + col) * 2) : OOB_OFF;
+            sstep[j] = 64u * (unsigned)C;
+        } else if (f < NF) {                 // W2 rows 16ct + i, columns 32s + 8g ..
+            const int ct = f - 2 * NK;
+            soff[j] = (unsigned)(((16 * ct + i16) * HD + 8 * g) * 2);
+            sstep[j] = 64u;
+        } else {
+            soff[j] = OOB_OFF;
+            sstep[j] = 0u;
+        }
+    }
+    u32x4 st[NLD];
+    auto load_slice = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int f = wave + WAVES * j;
+            st[j] = f < 2 * NK ? __builtin_amdgcn_raw_buffer_load_b128(rw1, soff[j] + sstep[j] * (unsigned)s, 0, 0)
+                               : __builtin_amdgcn_raw_buffer_load_b128(rw2, soff[j] + sstep[j] * (unsigned)s, 0, 0);
+        }
+    };
+    auto write_slice = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NLD; ++j) {
+            const int f = wave + WAVES * j;
+            if (f < NF) ring[(buf * NF + f) * 64 + lane] = st[j];
+        }
+    };
+    const int NS = HD >> 5;
+    load_slice(0);
+    for (int i = tid; i < HD; i += 64 * WAVES) sB1[i] = p.b1[i];
+    // ---- this wave's 32 tokens: LayerNorm -> B-operand fragments
+    const auto rx = MAKE_RSRC(p.x);
+    const auto ro = MAKE_RSRC(p.out);
+    const auto rgam = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gamma), 0, C * 4, 0x00020000);
+    const auto rbet = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.beta), 0, C * 4, 0x00020000);
+    const auto rb2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b2), 0, C * 4, 0x00020000);
+    const float inv_c = 1.f / (float)c_real, n_pad = (float)(32 * NK - c_real);
+    unsigned rbase[RT];
+    float sc[RT];
+    bf16x8 vf[RT][NK];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt) {
+        const int row = (blockIdx.x * WAVES + wave) * 16 * RT + 16 * rt + i16;
+        const bool ok = row < p.M;
+        rbase[rt] = ok ? (unsigned)row * (unsigned)(C * 2) : OOB_OFF;
+        sc[rt] = (p.scale && ok) ? p.scale[row / p.rows_per_sample] : 1.f;
+        u32x4 xr[NK];
+#pragma unroll
+        for (int k = 0; k < NK; ++k) xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && 32 * k + 8 * g < C) ? rbase[rt] + (32 * k + 8 * g) * 2 : OOB_OFF, 0, 0);
+        float v[NK][8];
+        float sm = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                v[k][2 * j] = blo(xr[k][j]);
+                v[k][2 * j + 1] = bhi(xr[k][j]);
+                sm += v[k][2 * j] + v[k][2 * j + 1];
+            }
+        sm = xor16_sum(sm);
+        sm = xor32_sum(sm);
+        const float mean = sm * inv_c;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                v[k][j] -= mean;
+                q += v[k][j] * v[k][j];
+            }
+        q = xor16_sum(q);
+        q = xor32_sum(q);
+        const float rstd = rsqrtf(fmaxf(q - n_pad * mean * mean, 0.f) * inv_c + p.eps);
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const f32x4 g0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgam, (32 * k + 8 * g) * 4, 0, 0));
+            const f32x4 g1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgam, (32 * k + 8 * g + 4) * 4, 0, 0));
+            const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbet, (32 * k + 8 * g) * 4, 0, 0));
+            const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbet, (32 * k + 8 * g + 4) * 4, 0, 0));
+            u32x4 o;
+            o[0] = pack_bf16x2(v[k][0] * rstd * g0[0] + b0[0], v[k][1] * rstd * g0[1] + b0[1]);
+            o[1] = pack_bf16x2(v[k][2] * rstd * g0[2] + b0[2], v[k][3] * rstd * g0[3] + b0[3]);
+            o[2] = pack_bf16x2(v[k][4] * rstd * g1[0] + b1[0], v[k][5] * rstd * g1[1] + b1[1]);
+            o[3] = pack_bf16x2(v[k][6] * rstd * g1[2] + b1[2], v[k][7] * rstd * g1[3] + b1[3]);
+            vf[rt][k] = __builtin_bit_cast(bf16x8, o);
+        }
+    }
+    write_slice(0);
+    if (NS > 1) load_slice(1);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 y[RT][NCT];
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) y[rt][ct] = zero;
+#pragma unroll 1
+    for (int s = 0; s < NS; ++s) {
+        __syncthreads();          // slice s is visible to everyone, everyone is done with the other slot (slice s - 1)
+        if (s + 1 < NS) write_slice((s + 1) & 1);
+        if (s + 2 < NS) load_slice(s + 2);
+        const u32x4* fr = ring + (s & 1) * NF * 64;
+        f32x4 h[RT][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const f32x4 bias = *reinterpret_cast<const f32x4*>(&sB1[32 * s + 8 * g + 4 * u]);     // b1[hid(2s + u, 4g + r)]
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) h[rt][u] = bias;
+        }
+#pragma unroll
+        for (int k = 0; k < NK; ++k)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const bf16x8 a = LDS_FRAG(fr, u * NK + k, lane);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) h[rt][u] = MFMA(a, vf[rt][k], h[rt][u]);
+            }
+        bf16x8 hf[RT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt) hf[rt] = pack2(gelu_erf(h[rt][0]), gelu_erf(h[rt][1]));
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const bf16x8 a = LDS_FRAG(fr, 2 * NK + ct, lane);
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) y[rt][ct] = MFMA(a, hf[rt], y[rt][ct]);
+        }
+    }
+#pragma unroll
+    for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+        for (int ct = 0; ct < NCT; ++ct) {
+            const unsigned off = rbase[rt] == OOB_OFF ? OOB_OFF : rbase[rt] + (16 * ct + 4 * g) * 2;
+            const u32x2 xo = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
+            const f32x4 b2v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb2, (16 * ct + 4 * g) * 4, 0, 0));
+            const f32x4 o = (y[rt][ct] + b2v) * sc[rt] + unpack4(xo);
+            __builtin_amdgcn_raw_buffer_store_b64(pack4(o), ro, off, 0, 0);
+        }
+}
+
 // ================================================================================================ backward: dx
 // dx = dy + LayerNorm_bwd( W1^T ( gelu'(z) * (W2^T (s dy)) ) ),  z = W1 LN(x) + b1 recomputed.  part[block][2][C] receives this
 // workgroup's sums of dv * xhat (dgamma) and dv (dbeta), dv = gradient w.r.t. the LayerNorm output.
@@ -1254,6 +1418,50 @@ extern "C" int pk_ln_mlp_fwd(const void* x, const float* gamma, const float* bet
     if (C == 32) hipLaunchKernelGGL(k_mlp_fwd<32>, grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_mlp_fwd<64>, grid, block, 0, (hipStream_t)stream, a);
     return pk_launch_status("pk_ln_mlp_fwd");
+}
+
+// Wide channels, forward only (inference; training of these widths takes the unfused sequence, whose backward needs the hidden saved).
+extern "C" int pk_ln_mlp_wide_supported(int C, int hidden) {
+    static const int on = getenv("PK_MLP_WIDE") ? atoi(getenv("PK_MLP_WIDE")) : 1;
+    return on && (C == 80 || C == 128 || C == 160 || C == 256 || C == 320) && hidden > 0 && hidden % 32 == 0 && hidden <= 2048;
+}
+template <int NK, int NCT, int WAVES>
+static int mlp_wide_launch(const MlpArgs& a, int C, int c_real, int HD, hipStream_t st) {
+    const int lds = 2 * (2 * NK + NCT) * 1024 + HD * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fwd_w<NK, NCT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * NK + NCT) * 1024 + 2048 * 4);
+        if (e != hipSuccess) {
+            pk_set_error("pk_ln_mlp_wide_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    const dim3 grid((a.M + 32 * WAVES - 1) / (32 * WAVES)), block(64 * WAVES);
+    hipLaunchKernelGGL((k_mlp_fwd_w<NK, NCT, WAVES>), grid, block, lds, st, a, C, c_real, HD);
+    return pk_launch_status("pk_ln_mlp_wide_fwd");
+}
+extern "C" int pk_ln_mlp_wide_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
+                                  const float* b2, const float* row_scale, void* y, int M, int C, int c_real, int hidden,
+                                  int rows_per_sample, float eps, void* stream) {
+    PK_SUPPORTED(pk_ln_mlp_wide_supported(C, hidden), "pk_ln_mlp_wide_fwd: C=%d hidden=%d (built for C = 80 / 128 / 160 / 256 / 320, hidden %% 32 == 0)", C, hidden);
+    PK_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && y && M > 0, "pk_ln_mlp_wide_fwd: null pointer / bad size");
+    PK_REQUIRE(c_real > 0 && c_real <= C, "pk_ln_mlp_wide_fwd: c_real=%d outside (0, C=%d]", c_real, C);
+    PK_REQUIRE(!row_scale || rows_per_sample > 0, "pk_ln_mlp_wide_fwd: scale needs rows_per_sample");
+    PK_REQUIRE((int64_t)M * C < 0x3fffffffLL && (int64_t)hidden * C < 0x1fffffffLL, "pk_ln_mlp_wide_fwd: tensor too large for 32-bit byte offsets");
+    PK_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)w1) | ((uintptr_t)w2) | ((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)b2)) & 15) == 0,
+               "pk_ln_mlp_wide_fwd: 16-byte alignment");
+    MlpArgs a{};
+    a.x = (const uint16_t*)x; a.out = (uint16_t*)y; a.gamma = gamma; a.beta = beta; a.b1 = b1; a.b2 = b2; a.scale = row_scale;
+    a.w1 = (const uint16_t*)w1; a.w2 = (const uint16_t*)w2; a.M = M; a.rows_per_sample = rows_per_sample > 0 ? rows_per_sample : 1; a.eps = eps;
+    hipStream_t st = (hipStream_t)stream;
+    switch (C) {
+        case 80: return mlp_wide_launch<3, 5, 8>(a, C, c_real, hidden, st);
+        case 128: return mlp_wide_launch<4, 8, 8>(a, C, c_real, hidden, st);
+        case 160: return mlp_wide_launch<5, 10, 8>(a, C, c_real, hidden, st);
+        case 256: return mlp_wide_launch<8, 16, 4>(a, C, c_real, hidden, st);
+        default: return mlp_wide_launch<10, 20, 4>(a, C, c_real, hidden, st);
+    }
 }
 
 extern "C" int pk_ln_mlp_bwd_dx(const void* dy, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,

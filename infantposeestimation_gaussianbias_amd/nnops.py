@@ -869,6 +869,24 @@ class _MlpHalfFused(torch.autograd.Function):
                 None if s_b2 else dbb2, None)
 
 
+def wide_mlp_enabled(C, hidden):
+    """Forward-only fused MLP half for the wide branches (C = 80 ... 320, weights streamed through LDS): pk_ln_mlp_wide_fwd.
+    POSE_FUSED_MLP_WIDE=0 switches it off (the unfused LayerNorm / fc1+GELU / fc2 sequence runs instead)."""
+    return os.environ.get("POSE_FUSED_MLP_WIDE", "1") != "0" and bool(_lib.lib.pk_ln_mlp_wide_supported(C, hidden))
+
+
+def mlp_half_wide_forward(x, g2, b2, w1, bias1, w2, bias2, scale2, c_real=0):
+    """x + s2 * fc2(gelu(fc1(LN2(x)))) in ONE launch for inference at C = 80 / 128 / 160 / 256 / 320 (hrformer.py:287-293, Mlp :38-64)."""
+    wc = _wc()
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    s2 = None if scale2 is None else scale2.float().contiguous()
+    y = _e((B, H, W, C), BF16, x.device)
+    call("pk_ln_mlp_wide_fwd", x, g2, b2, wc.fwd[id(w1)], bias1, wc.fwd[id(w2)], bias2, s2, y, B * H * W, C, c_real or C, w1.shape[0], H * W, 1e-5,
+         stream_ptr())
+    return y
+
+
 def fused_attn_enabled(C, heads, c_real=0, attn_scale=0.0, train=True):
     """POSE_FUSED_ATTN (training) / POSE_FUSED_ATTN_EVAL (forward only) = channel counts that take the fused attention half."""
     ok = c_real in (0, C) and not attn_scale and bool(_lib.lib.pk_attn_block_supported(C, heads))
@@ -967,6 +985,8 @@ def window_block(x, blk, heads, scale1=None, scale2=None):
         x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, rel_table(a, heads), a.qkv.weight, a.qkv.bias,
                             a.proj.weight, a.proj.bias, scale1, heads, c_real, attn_scale)
     m = blk.mlp
+    if not needs_grad and wide_mlp_enabled(x.shape[-1], m.fc1.weight.shape[0]):
+        return mlp_half_wide_forward(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2, c_real)
     if fused_mlp_enabled(x.shape[-1], c_real) and m.fc1.weight.shape[0] == 4 * x.shape[-1]:
         return _MlpHalfFused.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2)
     return _MlpHalf.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2, c_real)

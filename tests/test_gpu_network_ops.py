@@ -719,6 +719,59 @@ def test_fused_mlp_half_vs_torch_and_unfused(N, monkeypatch, Cc, B, H, W, scaled
         assert torch.equal(y[0], x[0].to(BF).float()) and torch.equal(gx[0], gy[0].to(BF).float())
 
 
+@pytest.mark.parametrize("Cc,c_real,hidden,B,H,W,scaled", [(80, 78, 320, 3, 9, 10, True), (128, 128, 512, 2, 16, 12, False),
+                                                           (160, 156, 640, 2, 7, 9, True), (256, 256, 1024, 3, 8, 6, True),
+                                                           (320, 312, 1280, 2, 5, 3, False), (80, 80, 320, 1, 1, 5, False),
+                                                           (128, 128, 256, 5, 33, 31, True), (160, 160, 96, 2, 24, 18, False)])
+def test_wide_fused_mlp_forward_vs_torch_and_unfused(N, Cc, c_real, hidden, B, H, W, scaled):
+    """pk_ln_mlp_wide_fwd (C = 80 ... 320: fc1 / fc2 weights streamed through an LDS ring in hidden slices of 32, forward only) against the
+    fp32 PyTorch reference of the half (LayerNorm over the REAL channels, zeros in the padded ones -- the padded twin's convention,
+    models/padded.py) at 8e-3 norm-wise (bf16 store), against the unfused kernel sequence at 2e-2, and the padded output channels stay 0."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    torch.manual_seed(Cc + H)
+    blk = HRFormerBlock(Cc, Cc // (40 if Cc % 40 == 0 else 32))
+    if hidden != 4 * Cc:
+        blk.mlp.fc1 = torch.nn.Linear(Cc, hidden)
+        blk.mlp.fc2 = torch.nn.Linear(hidden, Cc)
+    hr = hidden * c_real // Cc if c_real != Cc else hidden           # real hidden units of a padded twin
+    with torch.no_grad():
+        for n, p in blk.named_parameters():
+            p.copy_(q(p * 4) if p.dim() > 1 else q(p + 0.1 * torch.randn_like(p)))
+        if c_real != Cc:                                             # zero padding exactly as PaddedTwin embeds the real parameters
+            blk.norm2.weight[c_real:] = 0
+            blk.norm2.bias[c_real:] = 0
+            blk.mlp.fc1.weight[:, c_real:] = 0
+            blk.mlp.fc1.weight[hr:] = 0
+            blk.mlp.fc1.bias[hr:] = 0
+            blk.mlp.fc2.weight[c_real:] = 0
+            blk.mlp.fc2.weight[:, hr:] = 0
+            blk.mlp.fc2.bias[c_real:] = 0
+    x = q(torch.randn(B, H, W, Cc, generator=torch.Generator().manual_seed(1)) * 1.5 + 0.3)
+    x[..., c_real:] = 0
+    s2 = torch.tensor([0.0, 1 / 0.9, 1 / 0.9, 1 / 0.9, 0.0][:B]) if scaled else None
+    with torch.no_grad():
+        v = torch.zeros_like(x)
+        v[..., :c_real] = F.layer_norm(x[..., :c_real], (c_real,), blk.norm2.weight[:c_real], blk.norm2.bias[:c_real], 1e-5)
+        m = F.gelu(q(v) @ blk.mlp.fc1.weight.T + blk.mlp.fc1.bias) @ blk.mlp.fc2.weight.T + blk.mlp.fc2.bias
+        y_ref = x + (m if s2 is None else m * s2.view(-1, 1, 1, 1))
+    blk = blk.to(DEV)
+    m_ = blk.mlp
+    args = (blk.norm2.weight, blk.norm2.bias, m_.fc1.weight, m_.fc1.bias, m_.fc2.weight, m_.fc2.bias, None if s2 is None else s2.to(DEV))
+    xd = x.to(DEV, BF)
+    assert N.wide_mlp_enabled(Cc, hidden)
+    with torch.no_grad(), N.use_weights(blk):
+        y = N.mlp_half_wide_forward(xd, *args, c_real if c_real != Cc else 0)
+        yu = N._MlpHalf.apply(xd, *args, c_real if c_real != Cc else 0)
+    torch.cuda.synchronize()
+    print("wide fused mlp fwd vs fp32", err(C(y), y_ref), "vs unfused", err(C(y), C(yu)))
+    assert torch.isfinite(y.float()).all()
+    assert err(C(y), y_ref) < 8e-3 and err(C(y), C(yu)) < 2e-2
+    if c_real != Cc:
+        assert torch.count_nonzero(y[..., c_real:]) == 0
+    if s2 is not None:
+        assert torch.equal(C(y)[0], x[0].to(BF).float())
+
+
 # ------------------------------------------------------------------------------------------------ fused attention half (C = 32 / 64)
 @pytest.mark.parametrize("Cc,heads,B,H,W,scaled", [(32, 1, 2, 9, 10, True), (64, 2, 3, 8, 6, True), (32, 1, 2, 14, 7, False),
                                                   (64, 2, 2, 5, 9, False), (32, 1, 4, 64, 48, True)])

@@ -245,7 +245,7 @@ int pk_ln_mlp_fwd(const void* x, const float* gamma, const float* beta, const vo
 /* The same half for wide channels (C = 80 / 128 / 160 / 256 / 320; hrformer.py:262-293 with Mlp :38-64 at stage-3/4 widths and the
  * 8-aligned twin of HRFormer-base :779-825), forward only: fc1 / fc2 weights streamed through LDS in hidden slices of 32.  `c_real` <= C:
  * channels the LayerNorm statistics run over (the padded channels hold zeros).  w1 [hidden][C], w2 [C][hidden] bf16 row-major. */
-int pk_ln_mlp_wide_supported(int C, int hidden);
+int pk_ln_mlp_wide_supported(int C, int hidden, int M);   /* M > 0: ... and the launch has enough workgroups to pay (M = 0: built for?) */
 int pk_ln_mlp_wide_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                        const float* b2, const float* row_scale, void* y, int M, int C, int c_real, int hidden, int rows_per_sample,
                        float eps, void* stream);
@@ -255,6 +255,15 @@ int pk_ln_mlp_bwd_dx(const void* dy, const void* x, const float* gamma, const fl
 int pk_ln_mlp_bwd_dw(const void* dy, const void* x, const float* gamma, const float* beta, const void* w1, const float* b1,
                      const void* w2_t, const float* row_scale, float* slabs, int M, int C, int rows_per_sample, float eps,
                      void* stream);
+/* Attention half for the 8-aligned twin of HRFormer-base (hrformer.py:779-825: C = heads x 39, here heads x 40 with zero padding; block
+ * :262-286, WindowAttention :174-200), forward only: C = 80 with 2 heads.  wqkv [3][heads][40][C], wproj [C][heads][40] bf16, biases and
+ * LayerNorm parameters zero in the padded entries; `c_real` = channels the LayerNorm statistics run over, `softmax_scale` = real
+ * head_dim^-0.5.  `n_windows` > 0 in _supported additionally asks whether the launch has enough windows to pay. */
+int pk_attn_block_wide_supported(int C, int heads, int n_windows);
+int pk_attn_block_wide_fwd(const void* x, const int32_t* rowmap, const float* gamma, const float* beta, const float* rel_table,
+                           const void* wqkv, const float* bqkv, const void* wproj, const float* bproj, const float* row_scale,
+                           void* y, int n_windows, int windows_per_sample, int heads, int C, int c_real, float softmax_scale,
+                           float eps, void* stream);
 /* Fused attention half of the HRFormer block (hrformer.py:262-286 with WindowAttention :174-200, window_partition/reverse :67-114),
  * C = 32 / 64, head_dim 32, window 7:   y = x + row_scale[b] * proj( attention( qkv( LayerNorm(x) ) ) )     x, y: [M][C] bf16 pixel rows.
  * rowmap[windows*49]: pixel row of every window token, -1 for the reference's zero-pad tokens (LayerNorm output forced to 0, i.e.

@@ -942,6 +942,256 @@ __global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs p) {
     }
 }
 
+// ================================================================================================ attention half, head_dim 40: forward
+// The 8-aligned twin of HRFormer-base (models/padded.py: C = heads x 40, head_dim 39 zero-padded to 40; hrformer.py:779-825) at its
+// high-resolution widths.  Same chain as k_attn_fwd (one wave per 7x7 window, everything through MFMA accumulators), with the head
+// dimension on THREE 16-row tiles (40 real + 8 zero rows) and two 32-deep contraction steps over it:
+//   * q / k tiles et = 0..2: rows 16et + i of the head (rows >= 40: zero weights, zero bias); score operands = pack2(tile 0, tile 1) and
+//     pack2(tile 2, 0);
+//   * v tiles ce = 0, 1 gathered with hid() as before; tile 2 = head channels 32 + i, i < 8.  The packed output pack2(o[2], 0) then has
+//     slot jj < 4 of lane group g = head channel 32 + 4g + jj (g < 2): the second projection fragment holds exactly those four W_proj
+//     columns per lane (an 8-byte chunk, zero elsewhere);
+//   * K-steps over the input channels: NK = ceil(C / 32), columns >= C are out-of-range (zero) loads, as in k_mlp_fwd_w.
+// LayerNorm statistics over `c_real` channels (the padded channels of the twin hold zeros), softmax scale = p.softmax_scale (39^-0.5).
+// Forward only (inference): neither the attention output nor the log-sum-exp is saved.  All heads' weight fragments are resident in LDS
+// (C = 80: 74 KB), filled once per workgroup.
+template <int NK, int NCT, int HEADS>
+__global__ void __launch_bounds__(256) k_attn_fwd_w(AttnArgs p, int C, int c_real) {
+    constexpr int ET = 3, HDP = 40;
+    constexpr int F_QK = 2 * ET * NK, F_V = ET * NK, F_P = 2 * NCT, F_HEAD = F_QK + F_V + F_P;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
+    u32x4* sW = reinterpret_cast<u32x4*>(smem_a);                                   // [HEADS][F_HEAD][64]
+    float* sBqkv = reinterpret_cast<float*>(smem_a + HEADS * F_HEAD * 1024);         // [3C]
+    float* sBias = sBqkv + 3 * HEADS * HDP;                                          // [HEADS][176]
+    const int tid = threadIdx.x, lane_ = tid & 63, wave = tid >> 6, g_ = lane_ >> 4;
+    for (int idx = tid; idx < HEADS * F_HEAD * 64; idx += 256) {
+        const int f = idx >> 6, l = idx & 63, i = l & 15, gg = l >> 4, h = f / F_HEAD, fl = f - h * F_HEAD;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (fl < F_QK + F_V) {
+            int row, k;
+            if (fl < F_QK) {                                   // q / k tile et: head rows 16et + i
+                const int part = fl / (ET * NK), r = fl - part * ET * NK, et = r / NK;
+                k = r - et * NK;
+                const int e = 16 * et + i;
+                row = e < HDP ? part * C + HDP * h + e : -1;
+            } else {                                           // v tile ce
+                const int r = fl - F_QK, ce = r / NK;
+                k = r - ce * NK;
+                const int e = ce < 2 ? hid(ce, i) : (i < 8 ? 32 + i : HDP);
+                row = e < HDP ? 2 * C + HDP * h + e : -1;
+            }
+            const int col = 32 * k + 8 * gg;
+            if (row >= 0 && col < C) v = *reinterpret_cast<const u32x4*>(p.wqkv + (size_t)row * C + col);
+        } else {
+            const int r = fl - F_QK - F_V, ks = r / NCT, nt = r - ks * NCT;
+            const uint16_t* src = p.wproj + (size_t)(16 * nt + i) * C + HDP * h;
+            if (ks == 0) v = *reinterpret_cast<const u32x4*>(src + 8 * gg);
+            else if (gg < 2) {
+                const u32x2 t = *reinterpret_cast<const u32x2*>(src + 32 + 4 * gg);
+                v[0] = t[0];
+                v[1] = t[1];
+            }
+        }
+        sW[idx] = v;
+    }
+    for (int i = tid; i < 3 * C; i += 256) sBqkv[i] = p.bqkv[i];
+    for (int i = tid; i < HEADS * 169; i += 256) sBias[(i / 169) * 176 + i % 169] = p.table[(i % 169) * HEADS + i / 169];
+    int aj[4][4];                       // 84 - A(j) for this lane's 16 keys j = 16cj + 4g + r (-1: tile padding)
+#pragma unroll
+    for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int j = 16 * cj + 4 * g_ + r;
+            aj[cj][r] = j < AT_N ? 84 - rel_a7(j) : -1;
+        }
+    __syncthreads();
+    const auto rx = MAKE_RSRC(p.x);
+    const auto ro = MAKE_RSRC(p.out);
+    const auto rgam = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gamma), 0, C * 4, 0x00020000);
+    const auto rbet = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.beta), 0, C * 4, 0x00020000);
+    const auto rbp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bproj), 0, C * 4, 0x00020000);
+    const float inv_c = 1.f / (float)c_real, n_pad = (float)(32 * NK - c_real);
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int w = blockIdx.x * 4 + wave; w < p.n_windows; w += gridDim.x * 4) {
+        const int lane = opaque_lane<true>(lane_), i16 = lane & 15, g = lane >> 4;
+        int row[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int n = 16 * t + i16;
+            row[t] = n < AT_N ? p.rowmap[w * AT_N + n] : -1;
+        }
+        const float sc = p.scale ? p.scale[w / p.windows_per_sample] : 1.f;
+        bf16x8 uf[4][NK];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const unsigned base = row[t] >= 0 ? (unsigned)row[t] * (unsigned)(C * 2) : OOB_OFF;
+            u32x4 xr[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+                xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (row[t] >= 0 && 32 * k + 8 * g < C) ? base + (32 * k + 8 * g) * 2 : OOB_OFF, 0, 0);
+            float v[NK][8];
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[k][2 * j] = blo(xr[k][j]);
+                    v[k][2 * j + 1] = bhi(xr[k][j]);
+                    sm += v[k][2 * j] + v[k][2 * j + 1];
+                }
+            sm = xor16_sum(sm);
+            sm = xor32_sum(sm);
+            const float mean = sm * inv_c;
+            float qv = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[k][j] -= mean;
+                    qv += v[k][j] * v[k][j];
+                }
+            qv = xor16_sum(qv);
+            qv = xor32_sum(qv);
+            const float rstd = rsqrtf(fmaxf(qv - n_pad * mean * mean, 0.f) * inv_c + p.eps);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const f32x4 g0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgam, (32 * k + 8 * g) * 4, 0, 0));
+                const f32x4 g1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgam, (32 * k + 8 * g + 4) * 4, 0, 0));
+                const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbet, (32 * k + 8 * g) * 4, 0, 0));
+                const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbet, (32 * k + 8 * g + 4) * 4, 0, 0));
+                u32x4 o;
+                o[0] = pack_bf16x2(v[k][0] * rstd * g0[0] + b0[0], v[k][1] * rstd * g0[1] + b0[1]);
+                o[1] = pack_bf16x2(v[k][2] * rstd * g0[2] + b0[2], v[k][3] * rstd * g0[3] + b0[3]);
+                o[2] = pack_bf16x2(v[k][4] * rstd * g1[0] + b1[0], v[k][5] * rstd * g1[1] + b1[1]);
+                o[3] = pack_bf16x2(v[k][6] * rstd * g1[2] + b1[2], v[k][7] * rstd * g1[3] + b1[3]);
+                // zero-pad token (or tile padding): the reference pads AFTER LayerNorm
+                uf[t][k] = row[t] >= 0 ? __builtin_bit_cast(bf16x8, o) : (bf16x8){0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
+        f32x4 accY[4][NCT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) accY[t][ct] = zero;
+#pragma unroll 1
+        for (int h = 0; h < HEADS; ++h) {
+            const u32x4* hw = sW + h * F_HEAD * 64;
+            const float* hb = sBqkv + HDP * h;
+            bf16x8 kf[4][2], vt[2][ET];
+            {                                                   // V: D[token][e], packed over token tiles -> A operand V^T
+                f32x4 va[4][ET];
+#pragma unroll
+                for (int ce = 0; ce < ET; ++ce) {
+                    const int e = ce < 2 ? hid(ce, i16) : (i16 < 8 ? 32 + i16 : -1);
+                    const float bv = e >= 0 ? hb[2 * C + e] : 0.f;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) va[t][ce] = (f32x4){bv, bv, bv, bv};
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const bf16x8 wv = LDS_FRAG(hw, F_QK + ce * NK + k, lane);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) va[t][ce] = MFMA(uf[t][k], wv, va[t][ce]);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int ce = 0; ce < ET; ++ce) vt[s2][ce] = pack2(va[2 * s2][ce], va[2 * s2 + 1][ce]);
+            }
+            {                                                   // K: D[e][token]
+                f32x4 ka[4][ET];
+#pragma unroll
+                for (int et = 0; et < ET; ++et) {
+                    f32x4 bk = zero;
+                    if (et < 2 || g < 2) bk = *reinterpret_cast<const f32x4*>(&hb[C + 16 * et + 4 * g]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) ka[t][et] = bk;
+#pragma unroll
+                    for (int k = 0; k < NK; ++k) {
+                        const bf16x8 wk = LDS_FRAG(hw, (ET + et) * NK + k, lane);
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) ka[t][et] = MFMA(wk, uf[t][k], ka[t][et]);
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    kf[t][0] = pack2(ka[t][0], ka[t][1]);
+                    kf[t][1] = pack2(ka[t][2], zero);
+                }
+            }
+#pragma unroll
+            for (int ci = 0; ci < 4; ++ci) {
+                bf16x8 qf[2];
+                {                                               // Q of this query tile
+                    f32x4 qa[ET];
+#pragma unroll
+                    for (int et = 0; et < ET; ++et) {
+                        qa[et] = zero;
+                        if (et < 2 || g < 2) qa[et] = *reinterpret_cast<const f32x4*>(&hb[16 * et + 4 * g]);
+#pragma unroll
+                        for (int k = 0; k < NK; ++k) qa[et] = MFMA(LDS_FRAG(hw, et * NK + k, lane), uf[ci][k], qa[et]);
+                    }
+                    qf[0] = pack2(qa[0], qa[1]);
+                    qf[1] = pack2(qa[2], zero);
+                }
+                const int i = 16 * ci + i16;
+                const int ai = rel_a7(i < AT_N ? i : 0);
+                f32x4 st[4];
+#pragma unroll
+                for (int cj = 0; cj < 4; ++cj) {
+                    st[cj] = MFMA(kf[cj][0], qf[0], zero);
+                    st[cj] = MFMA(kf[cj][1], qf[1], st[cj]);
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float bv = sBias[h * 176 + ai + (aj[cj][r] >= 0 ? aj[cj][r] : 0)];
+                        st[cj][r] = aj[cj][r] >= 0 ? st[cj][r] * p.softmax_scale + bv : -INFINITY;
+                        mx = fmaxf(mx, st[cj][r]);
+                    }
+                mx = xor16_max(mx);
+                mx = xor32_max(mx);
+                float sum = 0.f;
+#pragma unroll
+                for (int cj = 0; cj < 4; ++cj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        st[cj][r] = __expf(st[cj][r] - mx);
+                        sum += st[cj][r];
+                    }
+                sum = xor16_sum(sum);
+                sum = xor32_sum(sum);
+                const float inv = 1.f / sum;
+                const bf16x8 p0 = pack2(st[0] * inv, st[1] * inv), p1 = pack2(st[2] * inv, st[3] * inv);
+                f32x4 o[ET];
+#pragma unroll
+                for (int ce = 0; ce < ET; ++ce) {
+                    o[ce] = MFMA(vt[0][ce], p0, zero);
+                    o[ce] = MFMA(vt[1][ce], p1, o[ce]);
+                }
+                const bf16x8 of0 = pack2(o[0], o[1]), of1 = pack2(o[2], zero);
+#pragma unroll
+                for (int nt = 0; nt < NCT; ++nt) {
+                    accY[ci][nt] = MFMA(LDS_FRAG(hw, F_QK + F_V + nt, lane), of0, accY[ci][nt]);
+                    accY[ci][nt] = MFMA(LDS_FRAG(hw, F_QK + F_V + NCT + nt, lane), of1, accY[ci][nt]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const unsigned off = row[t] >= 0 ? (unsigned)row[t] * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF;
+                const u32x2 xo = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
+                const f32x4 bp = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbp, (16 * ct + 4 * g) * 4, 0, 0));
+                const f32x4 v = (accY[t][ct] + bp) * sc + unpack4(xo);
+                __builtin_amdgcn_raw_buffer_store_b64(pack4(v), ro, off, 0, 0);
+            }
+    }
+}
+
 // ================================================================================================ attention half: backward
 // One wave per window again; LayerNorm, q, k, v are recomputed from x, the projection's data gradient dO = (s dy) W_p is
 // computed in-kernel, the attention core follows pk_attn.hip's two-pass formulation (P recomputed from the saved log-sum-exp in
@@ -1368,6 +1618,48 @@ extern "C" int pk_attn_block_fwd(const void* x, const int32_t* rowmap, const flo
     return pk_launch_status("pk_attn_block_fwd");
 }
 
+// Head_dim-40 twins, forward only.  `n_windows` > 0 also asks whether the launch has enough windows to pay (one wave per window).
+extern "C" int pk_attn_block_wide_supported(int C, int heads, int n_windows) {
+    static const int on = getenv("PK_ATTN_WIDE") ? atoi(getenv("PK_ATTN_WIDE")) : 1;
+    static const int min_win = getenv("PK_ATTN_WIDE_MIN_WINDOWS") ? atoi(getenv("PK_ATTN_WIDE_MIN_WINDOWS")) : 1024;
+    if (!(on && C == 80 && heads == 2)) return 0;
+    return n_windows <= 0 || n_windows >= min_win;
+}
+template <int NK, int NCT, int HEADS>
+static int attn_wide_launch(const AttnArgs& a, int C, int c_real, hipStream_t st) {
+    const int lds = HEADS * (3 * 3 * NK + 2 * NCT) * 1024 + 3 * C * 4 + HEADS * 176 * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_fwd_w<NK, NCT, HEADS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) {
+            pk_set_error("pk_attn_block_wide_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
+            return (int)e;
+        }
+        attr_set = true;
+    }
+    static const int cap = getenv("PK_ATTN_WIDE_WGS") ? atoi(getenv("PK_ATTN_WIDE_WGS")) : 256;
+    const int need = (a.n_windows + 3) / 4;
+    hipLaunchKernelGGL((k_attn_fwd_w<NK, NCT, HEADS>), dim3(need < cap ? need : cap), dim3(256), lds, st, a, C, c_real);
+    return pk_launch_status("pk_attn_block_wide_fwd");
+}
+extern "C" int pk_attn_block_wide_fwd(const void* x, const int32_t* rowmap, const float* gamma, const float* beta, const float* rel_table,
+                                      const void* wqkv, const float* bqkv, const void* wproj, const float* bproj, const float* row_scale,
+                                      void* y, int n_windows, int windows_per_sample, int heads, int C, int c_real, float softmax_scale,
+                                      float eps, void* stream) {
+    PK_SUPPORTED(pk_attn_block_wide_supported(C, heads, 0), "pk_attn_block_wide_fwd: C=%d heads=%d (built for C = 80 with 2 heads of 40)", C, heads);
+    PK_REQUIRE(x && rowmap && gamma && beta && rel_table && wqkv && bqkv && wproj && bproj && y && n_windows > 0, "pk_attn_block_wide_fwd: null pointer");
+    PK_REQUIRE(c_real > 0 && c_real <= C && softmax_scale > 0.f, "pk_attn_block_wide_fwd: c_real=%d / softmax_scale=%g", c_real, (double)softmax_scale);
+    PK_REQUIRE(!row_scale || windows_per_sample > 0, "pk_attn_block_wide_fwd: row_scale needs windows_per_sample");
+    PK_REQUIRE(((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)wqkv) | ((uintptr_t)wproj) | ((uintptr_t)gamma) | ((uintptr_t)beta) | ((uintptr_t)bproj)) & 15) == 0,
+               "pk_attn_block_wide_fwd: 16-byte alignment");
+    PK_REQUIRE((int64_t)n_windows * AT_N * 3 * C < 0x3fffffffLL, "pk_attn_block_wide_fwd: too large for 32-bit offsets");
+    AttnArgs a{};
+    a.x = (const uint16_t*)x; a.out = (uint16_t*)y; a.rowmap = rowmap; a.gamma = gamma; a.beta = beta; a.table = rel_table; a.bqkv = bqkv;
+    a.bproj = bproj; a.scale = row_scale; a.wqkv = (const uint16_t*)wqkv; a.wproj = (const uint16_t*)wproj;
+    a.n_windows = n_windows; a.windows_per_sample = windows_per_sample > 0 ? windows_per_sample : 1; a.eps = eps; a.softmax_scale = softmax_scale;
+    return attn_wide_launch<3, 5, 2>(a, C, c_real, (hipStream_t)stream);
+}
+
 // ================================================================================================ C-ABI
 static inline int mlp_hidden_slice(int C) {          // hidden units per blockIdx.y slice of the weight-gradient kernel
     static const int env = getenv("PK_MLP_HS") ? atoi(getenv("PK_MLP_HS")) : 0;
@@ -1421,9 +1713,16 @@ extern "C" int pk_ln_mlp_fwd(const void* x, const float* gamma, const float* bet
 }
 
 // Wide channels, forward only (inference; training of these widths takes the unfused sequence, whose backward needs the hidden saved).
-extern "C" int pk_ln_mlp_wide_supported(int C, int hidden) {
+// `M` > 0 also asks whether the launch pays: a workgroup walks ALL hidden slices for its 128 / 256 tokens, so a launch with few
+// workgroups is one long serial chain per CU -- measured in cfg 5 (HRFormer-base twin, B = 64 with the flip): C = 320 with 13 824 tokens
+// (108 workgroups) 151 us against ~70 us for the unfused fc1 + fc2 GEMMs (step 29.35 ms with it, 27.45 ms without), while C = 80
+// (864 workgroups) and C = 160 (216) win 2.4 ms per step.  Default: at least PK_MLP_WIDE_MIN_WGS = 160 workgroups.
+extern "C" int pk_ln_mlp_wide_supported(int C, int hidden, int M) {
     static const int on = getenv("PK_MLP_WIDE") ? atoi(getenv("PK_MLP_WIDE")) : 1;
-    return on && (C == 80 || C == 128 || C == 160 || C == 256 || C == 320) && hidden > 0 && hidden % 32 == 0 && hidden <= 2048;
+    static const int min_wgs = getenv("PK_MLP_WIDE_MIN_WGS") ? atoi(getenv("PK_MLP_WIDE_MIN_WGS")) : 160;
+    if (!(on && (C == 80 || C == 128 || C == 160 || C == 256 || C == 320) && hidden > 0 && hidden % 32 == 0 && hidden <= 2048)) return 0;
+    const int per_wg = C >= 256 ? 128 : 256;
+    return M <= 0 || (M + per_wg - 1) / per_wg >= min_wgs;
 }
 template <int NK, int NCT, int WAVES>
 static int mlp_wide_launch(const MlpArgs& a, int C, int c_real, int HD, hipStream_t st) {
@@ -1444,7 +1743,7 @@ static int mlp_wide_launch(const MlpArgs& a, int C, int c_real, int HD, hipStrea
 extern "C" int pk_ln_mlp_wide_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,
                                   const float* b2, const float* row_scale, void* y, int M, int C, int c_real, int hidden,
                                   int rows_per_sample, float eps, void* stream) {
-    PK_SUPPORTED(pk_ln_mlp_wide_supported(C, hidden), "pk_ln_mlp_wide_fwd: C=%d hidden=%d (built for C = 80 / 128 / 160 / 256 / 320, hidden %% 32 == 0)", C, hidden);
+    PK_SUPPORTED(pk_ln_mlp_wide_supported(C, hidden, 0), "pk_ln_mlp_wide_fwd: C=%d hidden=%d (built for C = 80 / 128 / 160 / 256 / 320, hidden %% 32 == 0)", C, hidden);
     PK_REQUIRE(x && gamma && beta && w1 && b1 && w2 && b2 && y && M > 0, "pk_ln_mlp_wide_fwd: null pointer / bad size");
     PK_REQUIRE(c_real > 0 && c_real <= C, "pk_ln_mlp_wide_fwd: c_real=%d outside (0, C=%d]", c_real, C);
     PK_REQUIRE(!row_scale || rows_per_sample > 0, "pk_ln_mlp_wide_fwd: scale needs rows_per_sample");

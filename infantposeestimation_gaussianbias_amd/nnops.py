@@ -869,10 +869,36 @@ class _MlpHalfFused(torch.autograd.Function):
                 None if s_b2 else dbb2, None)
 
 
-def wide_mlp_enabled(C, hidden):
-    """Forward-only fused MLP half for the wide branches (C = 80 ... 320, weights streamed through LDS): pk_ln_mlp_wide_fwd.
-    POSE_FUSED_MLP_WIDE=0 switches it off (the unfused LayerNorm / fc1+GELU / fc2 sequence runs instead)."""
-    return os.environ.get("POSE_FUSED_MLP_WIDE", "1") != "0" and bool(_lib.lib.pk_ln_mlp_wide_supported(C, hidden))
+def wide_mlp_enabled(C, hidden, M=0):
+    """Forward-only fused MLP half for the wide branches (C = 80 ... 320, weights streamed through LDS): pk_ln_mlp_wide_fwd.  With the
+    token count M the library also says whether the launch would pay (enough workgroups).  POSE_FUSED_MLP_WIDE=0 switches it off
+    (the unfused LayerNorm / fc1+GELU / fc2 sequence runs instead)."""
+    return os.environ.get("POSE_FUSED_MLP_WIDE", "1") != "0" and bool(_lib.lib.pk_ln_mlp_wide_supported(C, hidden, 0 if _wide_forced() else M))
+
+
+def _wide_forced():
+    """POSE_FUSED_WIDE_FORCE=1: take the wide fused halves whenever they are built for the shape, however small the launch (tests)."""
+    return os.environ.get("POSE_FUSED_WIDE_FORCE", "0") == "1"
+
+
+def wide_attn_enabled(C, heads, n_windows=0):
+    """Forward-only fused attention half of the head_dim-40 twins (pk_attn_block_wide_fwd); POSE_FUSED_ATTN_WIDE=0 switches it off."""
+    return os.environ.get("POSE_FUSED_ATTN_WIDE", "1") != "0" and bool(
+        _lib.lib.pk_attn_block_wide_supported(C, heads, 0 if _wide_forced() else n_windows))
+
+
+def attn_half_wide_forward(x, g1, b1, table, wqkv, bqkv, wproj, bproj, scale1, heads, c_real=0, attn_scale=0.0):
+    """x + s1 * proj(window_attention(qkv(LN1(x)))) in ONE launch for the 8-aligned twin of HRFormer-base (hrformer.py:262-286 at
+    C = heads x 40): LayerNorm statistics over `c_real` channels, softmax scale `attn_scale` (the real head_dim^-0.5)."""
+    wc = _wc()
+    x = x.contiguous()
+    B, H, W, C = x.shape
+    amap, nwin = window_rowmap(B, H, W, x.device)
+    y = _e((B, H, W, C), BF16, x.device)
+    s1 = None if scale1 is None else scale1.float().contiguous()
+    call("pk_attn_block_wide_fwd", x, amap, g1, b1, table, wc.fwd[id(wqkv)], bqkv, wc.fwd[id(wproj)], bproj, s1, y, B * nwin, nwin, heads, C,
+         c_real or C, attn_scale or float(C // heads) ** -0.5, 1e-5, stream_ptr())
+    return y
 
 
 def mlp_half_wide_forward(x, g2, b2, w1, bias1, w2, bias2, scale2, c_real=0):
@@ -974,7 +1000,10 @@ def window_block(x, blk, heads, scale1=None, scale2=None):
     a = blk.attn
     c_real, attn_scale = getattr(blk, "c_real", 0), getattr(blk, "attn_scale", 0.0)      # set on padded twins (models/padded.py)
     needs_grad = torch.is_grad_enabled() and (x.requires_grad or blk.norm1.weight.requires_grad)
-    if fused_attn_enabled(x.shape[-1], heads, c_real, attn_scale, train=needs_grad):
+    if not needs_grad and wide_attn_enabled(x.shape[-1], heads, x.shape[0] * -(-x.shape[1] // WS) * -(-x.shape[2] // WS)):
+        x = attn_half_wide_forward(x, blk.norm1.weight, blk.norm1.bias, rel_table(a, heads), a.qkv.weight, a.qkv.bias, a.proj.weight,
+                                   a.proj.bias, scale1, heads, c_real, attn_scale)
+    elif fused_attn_enabled(x.shape[-1], heads, c_real, attn_scale, train=needs_grad):
         if needs_grad:
             x = _AttnHalfFused.apply(x, blk.norm1.weight, blk.norm1.bias, rel_table(a, heads), a.qkv.weight, a.qkv.bias,
                                      a.proj.weight, a.proj.bias, scale1, heads)
@@ -985,7 +1014,7 @@ def window_block(x, blk, heads, scale1=None, scale2=None):
         x = _AttnHalf.apply(x, blk.norm1.weight, blk.norm1.bias, rel_table(a, heads), a.qkv.weight, a.qkv.bias,
                             a.proj.weight, a.proj.bias, scale1, heads, c_real, attn_scale)
     m = blk.mlp
-    if not needs_grad and wide_mlp_enabled(x.shape[-1], m.fc1.weight.shape[0]):
+    if not needs_grad and wide_mlp_enabled(x.shape[-1], m.fc1.weight.shape[0], x.numel() // x.shape[-1]):
         return mlp_half_wide_forward(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2, c_real)
     if fused_mlp_enabled(x.shape[-1], c_real) and m.fc1.weight.shape[0] == 4 * x.shape[-1]:
         return _MlpHalfFused.apply(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, scale2)

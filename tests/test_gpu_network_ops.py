@@ -772,6 +772,66 @@ def test_wide_fused_mlp_forward_vs_torch_and_unfused(N, Cc, c_real, hidden, B, H
         assert torch.equal(C(y)[0], x[0].to(BF).float())
 
 
+@pytest.mark.parametrize("Cc,heads,padded,B,H,W,scaled", [(80, 2, True, 2, 9, 10, True), (80, 2, False, 3, 8, 6, False), (80, 2, True, 2, 14, 7, False),
+                                                          (80, 2, True, 4, 24, 18, True), (80, 2, False, 1, 5, 9, True)])
+def test_wide_fused_attention_forward_vs_oracle_and_unfused(N, Cc, heads, padded, B, H, W, scaled):
+    """pk_attn_block_wide_fwd (head_dim 40 = the padded head_dim 39 of HRFormer-base: LN1 -> qkv -> window attention with rel-pos bias ->
+    proj -> DropPath residual in one launch, three 16-row head tiles) against the fp32 oracle block half of the REAL block (C = heads x 39
+    embedded in zero padding the way models/padded.py does, LayerNorm over the real channels, scale 39^-0.5) resp. of a plain head_dim-40
+    block, and against the unfused kernel sequence."""
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    from oracle import nets as onet
+    torch.manual_seed(Cc + H)
+    d, dp = (39, 40) if padded else (40, 40)
+    Cr = heads * d
+    real = HRFormerBlock(Cr, heads)
+    with torch.no_grad():
+        for n, p in real.named_parameters():
+            p.copy_(q(p * 4) if p.dim() > 1 else q(p + 0.1 * torch.randn_like(p)))
+        real.attn.relative_position_bias_table.copy_(q(torch.randn(169, heads) * 0.5))
+    xr = q(torch.randn(B, H, W, Cr, generator=torch.Generator().manual_seed(1)) * 1.5 + 0.2)
+    s1 = torch.tensor([0.0, 1 / 0.9, 1 / 0.9, 1 / 0.9][:B]) if scaled else None
+    P = {"b." + k: v.detach().clone() for k, v in real.state_dict().items()}
+    with torch.no_grad():
+        u = F.layer_norm(xr, (Cr,), P["b.norm1.weight"], P["b.norm1.bias"], 1e-5)
+        tok, (Hp, Wp) = onet.to_windows(q(u))
+        a = onet.from_windows(onet.window_attention(tok, P, "b.attn", heads), B, H, W, Hp, Wp)
+        y_ref = xr + (a if s1 is None else a * s1.view(B, 1, 1, 1))
+    # the twin, embedded as models/padded.py does: plain tensors zero-extended at the end (x, LayerNorm, qkv input columns, proj output rows),
+    # the head dimension padded per head (qkv output rows, proj input columns: entry 39 of every head is zero)
+    twin = HRFormerBlock(Cc, heads)
+    hsel = torch.cat([torch.arange(d) + dp * h for h in range(heads)])
+    with torch.no_grad():
+        for p in twin.parameters():
+            p.zero_()
+        twin.norm1.weight[:Cr] = real.norm1.weight
+        twin.norm1.bias[:Cr] = real.norm1.bias
+        rows3 = torch.cat([hsel + part * Cc for part in range(3)])
+        twin.attn.qkv.weight[rows3, :Cr] = real.attn.qkv.weight
+        twin.attn.qkv.bias[rows3] = real.attn.qkv.bias
+        twin.attn.proj.weight[:Cr, hsel] = real.attn.proj.weight
+        twin.attn.proj.bias[:Cr] = real.attn.proj.bias
+        twin.attn.relative_position_bias_table.copy_(real.attn.relative_position_bias_table)
+    x = torch.zeros(B, H, W, Cc)
+    x[..., :Cr] = xr
+    twin = twin.to(DEV)
+    a_ = twin.attn
+    c_real, attn_scale = (Cr, float(d) ** -0.5) if padded else (0, 0.0)
+    args = (twin.norm1.weight, twin.norm1.bias, a_.relative_position_bias_table, a_.qkv.weight, a_.qkv.bias, a_.proj.weight, a_.proj.bias,
+            None if s1 is None else s1.to(DEV), heads)
+    xd = x.to(DEV, BF)
+    assert N.wide_attn_enabled(Cc, heads)
+    with torch.no_grad(), N.use_weights(twin):
+        y = N.attn_half_wide_forward(xd, *args, c_real, attn_scale)
+        yu = N._AttnHalf.apply(xd, *args, c_real, attn_scale)
+    torch.cuda.synchronize()
+    e_ref, e_unf = err(C(y)[..., :Cr], y_ref), err(C(y), C(yu))
+    print("wide fused attn fwd vs fp32", e_ref, "vs unfused", e_unf)
+    assert torch.isfinite(y.float()).all()
+    assert e_ref < 1.5e-2 and e_unf < 1.5e-2
+    assert torch.count_nonzero(y[..., Cr:]) == 0
+
+
 # ------------------------------------------------------------------------------------------------ fused attention half (C = 32 / 64)
 @pytest.mark.parametrize("Cc,heads,B,H,W,scaled", [(32, 1, 2, 9, 10, True), (64, 2, 3, 8, 6, True), (32, 1, 2, 14, 7, False),
                                                   (64, 2, 2, 5, 9, False), (32, 1, 4, 64, 48, True)])

@@ -34,6 +34,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define OOB_OFF 0x80000000u
 #define MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptr), 0, 0x7ffffff0, 0x00020000)
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")     // this wave's LDS writes are visible to its own reads
 
 struct MlpArgs {
@@ -248,6 +249,9 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(MlpArgs p) {
 // loads of x, gamma, beta and of the weight columns are out of range there.  `c_real` < C (padded twins, models/padded.py): the
 // LayerNorm statistics run over the real channels -- the padded ones hold exact zeros, so the sums only need the divisor, and the
 // squared-deviation sum is corrected by (32 NK - c_real) mean^2.
+#ifndef PK_MLP_WIDE_GELU_POLY
+#define PK_MLP_WIDE_GELU_POLY 1
+#endif
 template <int NK, int NCT, int WAVES>
 __global__ void __launch_bounds__(64 * WAVES) k_mlp_fwd_w(MlpArgs p, int C, int c_real, int HD) {
     constexpr int RT = 2, NF = 2 * NK + NCT, NLD = (NF + WAVES - 1) / WAVES;
@@ -381,7 +385,13 @@ __global__ void __launch_bounds__(64 * WAVES) k_mlp_fwd_w(MlpArgs p, int C, int 
             }
         bf16x8 hf[RT];
 #pragma unroll
-        for (int rt = 0; rt < RT; ++rt) hf[rt] = pack2(gelu_erf(h[rt][0]), gelu_erf(h[rt][1]));
+        for (int rt = 0; rt < RT; ++rt) {
+#if PK_MLP_WIDE_GELU_POLY
+            hf[rt] = pack2(gelu_erf_poly(h[rt][0]), gelu_erf_poly(h[rt][1]));          // packed-fp32 polynomial form (pk_common.h)
+#else
+            hf[rt] = pack2(gelu_erf(h[rt][0]), gelu_erf(h[rt][1]));
+#endif
+        }
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             const bf16x8 a = LDS_FRAG(fr, 2 * NK + ct, lane);
@@ -956,12 +966,13 @@ __global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs p) {
 // Forward only (inference): neither the attention output nor the log-sum-exp is saved.  All heads' weight fragments are resident in LDS
 // (C = 80: 74 KB), filled once per workgroup.
 template <int NK, int NCT, int HEADS>
-__global__ void __launch_bounds__(256) k_attn_fwd_w(AttnArgs p, int C, int c_real) {
+__global__ void __launch_bounds__(256, 2) k_attn_fwd_w(AttnArgs p, int C, int c_real) {
     constexpr int ET = 3, HDP = 40;
-    constexpr int F_QK = 2 * ET * NK, F_V = ET * NK, F_P = 2 * NCT, F_HEAD = F_QK + F_V + F_P;
+    constexpr int F_QK = 2 * ET * NK, F_V = ET * NK, F_P = NCT, F_HEAD = F_QK + F_V + F_P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
-    u32x4* sW = reinterpret_cast<u32x4*>(smem_a);                                   // [HEADS][F_HEAD][64]
-    float* sBqkv = reinterpret_cast<float*>(smem_a + HEADS * F_HEAD * 1024);         // [3C]
+    u32x4* sW = reinterpret_cast<u32x4*>(smem_a);                                   // [HEADS][F_HEAD][64]: 16-byte fragments
+    u32x2* sP2 = reinterpret_cast<u32x2*>(smem_a + HEADS * F_HEAD * 1024);           // [HEADS][NCT][64]: W_proj columns 32 + 4g .. of the head
+    float* sBqkv = reinterpret_cast<float*>(smem_a + HEADS * (F_HEAD * 1024 + NCT * 512));      // [3C]
     float* sBias = sBqkv + 3 * HEADS * HDP;                                          // [HEADS][176]
     const int tid = threadIdx.x, lane_ = tid & 63, wave = tid >> 6, g_ = lane_ >> 4;
     for (int idx = tid; idx < HEADS * F_HEAD * 64; idx += 256) {
@@ -983,27 +994,29 @@ __global__ void __launch_bounds__(256) k_attn_fwd_w(AttnArgs p, int C, int c_rea
             const int col = 32 * k + 8 * gg;
             if (row >= 0 && col < C) v = *reinterpret_cast<const u32x4*>(p.wqkv + (size_t)row * C + col);
         } else {
-            const int r = fl - F_QK - F_V, ks = r / NCT, nt = r - ks * NCT;
-            const uint16_t* src = p.wproj + (size_t)(16 * nt + i) * C + HDP * h;
-            if (ks == 0) v = *reinterpret_cast<const u32x4*>(src + 8 * gg);
-            else if (gg < 2) {
-                const u32x2 t = *reinterpret_cast<const u32x2*>(src + 32 + 4 * gg);
-                v[0] = t[0];
-                v[1] = t[1];
-            }
+            const int nt = fl - F_QK - F_V;
+            v = *reinterpret_cast<const u32x4*>(p.wproj + (size_t)(16 * nt + i) * C + HDP * h + 8 * gg);
         }
         sW[idx] = v;
     }
+    for (int idx = tid; idx < HEADS * NCT * 64; idx += 256) {
+        const int f = idx >> 6, l = idx & 63, i = l & 15, gg = l >> 4, h = f / NCT, nt = f - h * NCT;
+        u32x2 v = {0u, 0u};
+        if (gg < 2) v = *reinterpret_cast<const u32x2*>(p.wproj + (size_t)(16 * nt + i) * C + HDP * h + 32 + 4 * gg);
+        sP2[idx] = v;
+    }
     for (int i = tid; i < 3 * C; i += 256) sBqkv[i] = p.bqkv[i];
     for (int i = tid; i < HEADS * 169; i += 256) sBias[(i / 169) * 176 + i % 169] = p.table[(i % 169) * HEADS + i / 169];
-    int aj[4][4];                       // 84 - A(j) for this lane's 16 keys j = 16cj + 4g + r (-1: tile padding)
+    unsigned ajp[4];                    // bytes r = 0..3: 84 - A(j) for this lane's keys j = 16cj + 4g + r (255: tile padding)
 #pragma unroll
-    for (int cj = 0; cj < 4; ++cj)
+    for (int cj = 0; cj < 4; ++cj) {
+        ajp[cj] = 0u;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int j = 16 * cj + 4 * g_ + r;
-            aj[cj][r] = j < AT_N ? 84 - rel_a7(j) : -1;
+            ajp[cj] |= (unsigned)(j < AT_N ? 84 - rel_a7(j) : 255) << (8 * r);
         }
+    }
     __syncthreads();
     const auto rx = MAKE_RSRC(p.x);
     const auto ro = MAKE_RSRC(p.out);
@@ -1077,7 +1090,8 @@ __global__ void __launch_bounds__(256) k_attn_fwd_w(AttnArgs p, int C, int c_rea
         for (int h = 0; h < HEADS; ++h) {
             const u32x4* hw = sW + h * F_HEAD * 64;
             const float* hb = sBqkv + HDP * h;
-            bf16x8 kf[4][2], vt[2][ET];
+            bf16x8 kf[4], vt[2][ET];
+            s16x4 kf2[4];
             {                                                   // V: D[token][e], packed over token tiles -> A operand V^T
                 f32x4 va[4][ET];
 #pragma unroll
@@ -1115,13 +1129,14 @@ __global__ void __launch_bounds__(256) k_attn_fwd_w(AttnArgs p, int C, int c_rea
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    kf[t][0] = pack2(ka[t][0], ka[t][1]);
-                    kf[t][1] = pack2(ka[t][2], zero);
+                    kf[t] = pack2(ka[t][0], ka[t][1]);
+                    kf2[t] = __builtin_bit_cast(s16x4, pack4(ka[t][2]));       // head rows 32 + 4g + r: the K = 16 operand layout
                 }
             }
 #pragma unroll
             for (int ci = 0; ci < 4; ++ci) {
-                bf16x8 qf[2];
+                bf16x8 qf;
+                s16x4 qf2;
                 {                                               // Q of this query tile
                     f32x4 qa[ET];
 #pragma unroll
@@ -1131,24 +1146,27 @@ __global__ void __launch_bounds__(256) k_attn_fwd_w(AttnArgs p, int C, int c_rea
 #pragma unroll
                         for (int k = 0; k < NK; ++k) qa[et] = MFMA(LDS_FRAG(hw, et * NK + k, lane), uf[ci][k], qa[et]);
                     }
-                    qf[0] = pack2(qa[0], qa[1]);
-                    qf[1] = pack2(qa[2], zero);
+                    qf = pack2(qa[0], qa[1]);
+                    qf2 = __builtin_bit_cast(s16x4, pack4(qa[2]));
                 }
                 const int i = 16 * ci + i16;
                 const int ai = rel_a7(i < AT_N ? i : 0);
                 f32x4 st[4];
 #pragma unroll
-                for (int cj = 0; cj < 4; ++cj) {
-                    st[cj] = MFMA(kf[cj][0], qf[0], zero);
-                    st[cj] = MFMA(kf[cj][1], qf[1], st[cj]);
-                }
+                for (int cj = 0; cj < 4; ++cj) st[cj] = MFMA(kf[cj], qf, zero);
+                // (separate loops on purpose: hipcc 7.2 does not pad  v_mfma_f32_16x16x32_bf16 D, ..  directly followed by
+                //  v_mfma_f32_16x16x16_bf16 D', .., C = D  with D' != D -- the second reads a stale C; seen as 0.77 relative error in the
+                //  projection below when the two were issued back to back per output tile)
+#pragma unroll
+                for (int cj = 0; cj < 4; ++cj) st[cj] = MFMA16(kf2[cj], qf2, st[cj]);
                 float mx = -INFINITY;
 #pragma unroll
                 for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float bv = sBias[h * 176 + ai + (aj[cj][r] >= 0 ? aj[cj][r] : 0)];
-                        st[cj][r] = aj[cj][r] >= 0 ? st[cj][r] * p.softmax_scale + bv : -INFINITY;
+                        const int a = (int)((ajp[cj] >> (8 * r)) & 255u);
+                        const float bv = sBias[h * 176 + ai + (a != 255 ? a : 0)];
+                        st[cj][r] = a != 255 ? st[cj][r] * p.softmax_scale + bv : -INFINITY;
                         mx = fmaxf(mx, st[cj][r]);
                     }
                 mx = xor16_max(mx);
@@ -1171,12 +1189,13 @@ __global__ void __launch_bounds__(256) k_attn_fwd_w(AttnArgs p, int C, int c_rea
                     o[ce] = MFMA(vt[0][ce], p0, zero);
                     o[ce] = MFMA(vt[1][ce], p1, o[ce]);
                 }
-                const bf16x8 of0 = pack2(o[0], o[1]), of1 = pack2(o[2], zero);
+                const bf16x8 of0 = pack2(o[0], o[1]);
+                const s16x4 of1 = __builtin_bit_cast(s16x4, pack4(o[2]));
 #pragma unroll
-                for (int nt = 0; nt < NCT; ++nt) {
-                    accY[ci][nt] = MFMA(LDS_FRAG(hw, F_QK + F_V + nt, lane), of0, accY[ci][nt]);
-                    accY[ci][nt] = MFMA(LDS_FRAG(hw, F_QK + F_V + NCT + nt, lane), of1, accY[ci][nt]);
-                }
+                for (int nt = 0; nt < NCT; ++nt) accY[ci][nt] = MFMA(LDS_FRAG(hw, F_QK + F_V + nt, lane), of0, accY[ci][nt]);
+#pragma unroll
+                for (int nt = 0; nt < NCT; ++nt)
+                    accY[ci][nt] = MFMA16(__builtin_bit_cast(s16x4, sP2[(h * NCT + nt) * 64 + lane]), of1, accY[ci][nt]);
             }
         }
 #pragma unroll
@@ -1627,7 +1646,7 @@ extern "C" int pk_attn_block_wide_supported(int C, int heads, int n_windows) {
 }
 template <int NK, int NCT, int HEADS>
 static int attn_wide_launch(const AttnArgs& a, int C, int c_real, hipStream_t st) {
-    const int lds = HEADS * (3 * 3 * NK + 2 * NCT) * 1024 + 3 * C * 4 + HEADS * 176 * 4;
+    const int lds = HEADS * ((3 * 3 * NK + NCT) * 1024 + NCT * 512) + 3 * C * 4 + HEADS * 176 * 4;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)k_attn_fwd_w<NK, NCT, HEADS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
@@ -1637,7 +1656,7 @@ static int attn_wide_launch(const AttnArgs& a, int C, int c_real, hipStream_t st
         }
         attr_set = true;
     }
-    static const int cap = getenv("PK_ATTN_WIDE_WGS") ? atoi(getenv("PK_ATTN_WIDE_WGS")) : 256;
+    static const int cap = getenv("PK_ATTN_WIDE_WGS") ? atoi(getenv("PK_ATTN_WIDE_WGS")) : 512;
     const int need = (a.n_windows + 3) / 4;
     hipLaunchKernelGGL((k_attn_fwd_w<NK, NCT, HEADS>), dim3(need < cap ? need : cap), dim3(256), lds, st, a, C, c_real);
     return pk_launch_status("pk_attn_block_wide_fwd");

@@ -97,6 +97,7 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
 #ifndef PK_GELU_POLY
 #define PK_GELU_POLY 0
 #endif
+typedef __attribute__((ext_vector_type(4))) float pk_f32x4;
 #if !PK_GELU_POLY
 struct GeluTerms { float hw, e; };
 __device__ __forceinline__ GeluTerms gelu_terms(float x) {
@@ -124,7 +125,7 @@ __device__ __forceinline__ void gelu_both(float x, float& val, float& grad) {
     val = __fmaf_rn(-fabsf(x), g.hw, fmaxf(x, 0.f));
     grad = __fmaf_rn(x * 0.39894228040143267794f, g.e, gelu_cdf(x, g.hw));
 }
-typedef __attribute__((ext_vector_type(4))) float pk_f32x4;          // componentwise forms (A/B builds with -DPK_GELU_POLY=0)
+// componentwise 4-wide forms
 __device__ __forceinline__ pk_f32x4 gelu_erf(pk_f32x4 x) { return (pk_f32x4){gelu_erf(x[0]), gelu_erf(x[1]), gelu_erf(x[2]), gelu_erf(x[3])}; }
 __device__ __forceinline__ pk_f32x4 gelu_grad(pk_f32x4 x) { return (pk_f32x4){gelu_grad(x[0]), gelu_grad(x[1]), gelu_grad(x[2]), gelu_grad(x[3])}; }
 __device__ __forceinline__ void gelu_both(pk_f32x4 x, pk_f32x4& val, pk_f32x4& grad) {
@@ -136,15 +137,15 @@ __device__ __forceinline__ void gelu_both(pk_f32x4 x, pk_f32x4& val, pk_f32x4& g
         grad[i] = b;
     }
 }
-#else
-// Experiment (round 3): the rcp and the exp of that form are quarter-rate instructions (together as expensive as the eleven plain ones), and
-// none of it maps onto the packed fp32 pipe.  erf(x / sqrt 2) = xc P(xc^2), xc = clamp(x, -4.2, 4.2), P of degree 8 (minimax fit of
-// this file's author, scripts/fit_gelu_poly.py; |error| <= 1.5e-5 inside the interval, 2.7e-5 = 1 - erf(4.2 / sqrt 2) beyond it;
-// gelu: <= 4.4e-5 absolute, gelu': <= 1.1e-5 -- two orders of magnitude below the bf16 rounding of the tensors the results are
-// stored to): one v_med3 + multiplies and FMAs only, and in the 4-wide form (an MFMA accumulator tile) every multiply / FMA is a
-// v_pk_mul_f32 / v_pk_fma_f32 on two values: 7.5 issue slots per value instead of 19.  The scalar and the 4-wide form round
-// identically (same FMA chain per value).
-typedef __attribute__((ext_vector_type(4))) float pk_f32x4;
+#endif
+// The rcp and the exp of the form above are quarter-rate instructions (together as expensive as its eleven plain ones), and none of it maps
+// onto the packed fp32 pipe.  erf(x / sqrt 2) = xc P(xc^2), xc = clamp(x, -4.2, 4.2), P of degree 8 (minimax fit, scripts/fit_gelu_poly.py;
+// |error| <= 1.5e-5 inside the interval, 2.7e-5 = 1 - erf(4.2 / sqrt 2) beyond it; gelu: <= 4.4e-5 absolute, gelu': <= 1.1e-5 -- two
+// orders of magnitude below the bf16 rounding of the tensors the results are stored to): one v_med3 + multiplies and FMAs only, and in the
+// 4-wide form (an MFMA accumulator tile) every multiply / FMA is a v_pk_mul_f32 / v_pk_fma_f32 on two values: 7.5 issue slots per value
+// instead of 19.  Used where GELU is the measured bound: the forward-only wide MLP kernel (k_mlp_fwd_w: 70 M hidden elements per launch
+// at C = 80, 38 of its 83 us).  The training kernels keep the A&S form (measured there: no gain in the step, and their hidden is recomputed
+// in backward with the same function either way); -DPK_GELU_POLY=1 switches every call site over (A/B builds).
 #define PK_GELU_CLAMP 4.2f
 #define PK_GELU_C0 0.79781485f
 #define PK_GELU_C1 -0.13272066f
@@ -183,14 +184,17 @@ __device__ __forceinline__ pk_f32x4 erf_rsqrt2(pk_f32x4 x) {
     q = __builtin_elementwise_fma(q, s, (pk_f32x4)(PK_GELU_C0));
     return xc * q;
 }
-__device__ __forceinline__ float gelu_erf(float x) {
+__device__ __forceinline__ float gelu_erf_poly(float x) {
     const float h = 0.5f * x;
     return __fmaf_rn(h, erf_rsqrt2(x), h);
 }
-__device__ __forceinline__ pk_f32x4 gelu_erf(pk_f32x4 x) {
+__device__ __forceinline__ pk_f32x4 gelu_erf_poly(pk_f32x4 x) {
     const pk_f32x4 h = x * 0.5f;
     return __builtin_elementwise_fma(h, erf_rsqrt2(x), h);
 }
+#if PK_GELU_POLY
+__device__ __forceinline__ float gelu_erf(float x) { return gelu_erf_poly(x); }
+__device__ __forceinline__ pk_f32x4 gelu_erf(pk_f32x4 x) { return gelu_erf_poly(x); }
 // gelu'(x) = Phi(x) + x exp(-x^2 / 2) / sqrt(2 pi)
 __device__ __forceinline__ float gelu_grad(float x) {
     const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.44269504088896340736f));
@@ -204,7 +208,6 @@ __device__ __forceinline__ pk_f32x4 gelu_grad(pk_f32x4 x) {
     const pk_f32x4 cdf = __builtin_elementwise_fma((pk_f32x4)(0.5f), erf_rsqrt2(x), (pk_f32x4)(0.5f));
     return __builtin_elementwise_fma(x * 0.39894228040143267794f, e, cdf);
 }
-// value and derivative from one evaluation of the shared terms
 __device__ __forceinline__ void gelu_both(float x, float& val, float& grad) {
     const float er = erf_rsqrt2(x), h = 0.5f * x;
     const float e = __builtin_amdgcn_exp2f((x * x) * (-0.5f * 1.44269504088896340736f));

@@ -35,6 +35,8 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 #define MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptr), 0, 0x7ffffff0, 0x00020000)
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
+#define LO4(v) __builtin_shufflevector(v, v, 0, 1, 2, 3)        // the two 16-deep operands inside a 32-deep one
+#define HI4(v) __builtin_shufflevector(v, v, 4, 5, 6, 7)
 #define LDS_FENCE() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")     // this wave's LDS writes are visible to its own reads
 
 struct MlpArgs {
@@ -252,12 +254,15 @@ __global__ void __launch_bounds__(256) k_mlp_fwd(MlpArgs p) {
 #ifndef PK_MLP_WIDE_GELU_POLY
 #define PK_MLP_WIDE_GELU_POLY 1
 #endif
-template <int NK, int NCT, int WAVES>
+// RESIDENT (C = 80 with hidden 320: 110 KB of fragments): every slice is staged ONCE per workgroup, the workgroups are persistent over
+// 32-token groups and the waves run through the slices on their own -- no barrier after the prologue.
+template <int NK, int NCT, int WAVES, bool RESIDENT>
 __global__ void __launch_bounds__(64 * WAVES) k_mlp_fwd_w(MlpArgs p, int C, int c_real, int HD) {
     constexpr int RT = 2, NF = 2 * NK + NCT, NLD = (NF + WAVES - 1) / WAVES;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
-    u32x4* ring = reinterpret_cast<u32x4*>(smem_w);                      // [2][NF][64] fragments of the slice being multiplied / staged
-    float* sB1 = reinterpret_cast<float*>(smem_w + 2 * NF * 1024);       // [HD]
+    const int NS = HD >> 5, n_slots = RESIDENT ? NS : 2;
+    u32x4* ring = reinterpret_cast<u32x4*>(smem_w);                      // [n_slots][NF][64] fragments
+    float* sB1 = reinterpret_cast<float*>(smem_w + n_slots * NF * 1024); // [HD]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i16 = lane & 15, g = lane >> 4;
     const auto rw1 = MAKE_RSRC(p.w1), rw2 = MAKE_RSRC(p.w2);
     // staging: fragment f = wave + WAVES j of a slice is fetched by this wave (lane l = the fragment's lane)
@@ -287,128 +292,148 @@ __global__ void __launch_bounds__(64 * WAVES) k_mlp_fwd_w(MlpArgs p, int C, int 
                                : __builtin_amdgcn_raw_buffer_load_b128(rw2, soff[j] + sstep[j] * (unsigned)s, 0, 0);
         }
     };
-    auto write_slice = [&](int buf) {
+    auto write_slice = [&](int slot) {
 #pragma unroll
         for (int j = 0; j < NLD; ++j) {
             const int f = wave + WAVES * j;
-            if (f < NF) ring[(buf * NF + f) * 64 + lane] = st[j];
+            if (f < NF) ring[(slot * NF + f) * 64 + lane] = st[j];
         }
     };
-    const int NS = HD >> 5;
     load_slice(0);
     for (int i = tid; i < HD; i += 64 * WAVES) sB1[i] = p.b1[i];
-    // ---- this wave's 32 tokens: LayerNorm -> B-operand fragments
+    if (RESIDENT) {
+        for (int s = 0; s < NS; ++s) {
+            write_slice(s);
+            if (s + 1 < NS) load_slice(s + 1);
+        }
+        __syncthreads();
+    }
     const auto rx = MAKE_RSRC(p.x);
     const auto ro = MAKE_RSRC(p.out);
     const auto rgam = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.gamma), 0, C * 4, 0x00020000);
     const auto rbet = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.beta), 0, C * 4, 0x00020000);
     const auto rb2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.b2), 0, C * 4, 0x00020000);
     const float inv_c = 1.f / (float)c_real, n_pad = (float)(32 * NK - c_real);
-    unsigned rbase[RT];
-    float sc[RT];
-    bf16x8 vf[RT][NK];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt) {
-        const int row = (blockIdx.x * WAVES + wave) * 16 * RT + 16 * rt + i16;
-        const bool ok = row < p.M;
-        rbase[rt] = ok ? (unsigned)row * (unsigned)(C * 2) : OOB_OFF;
-        sc[rt] = (p.scale && ok) ? p.scale[row / p.rows_per_sample] : 1.f;
-        u32x4 xr[NK];
-#pragma unroll
-        for (int k = 0; k < NK; ++k) xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && 32 * k + 8 * g < C) ? rbase[rt] + (32 * k + 8 * g) * 2 : OOB_OFF, 0, 0);
-        float v[NK][8];
-        float sm = 0.f;
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                v[k][2 * j] = blo(xr[k][j]);
-                v[k][2 * j + 1] = bhi(xr[k][j]);
-                sm += v[k][2 * j] + v[k][2 * j + 1];
-            }
-        sm = xor16_sum(sm);
-        sm = xor32_sum(sm);
-        const float mean = sm * inv_c;
-        float q = 0.f;
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                v[k][j] -= mean;
-                q += v[k][j] * v[k][j];
-            }
-        q = xor16_sum(q);
-        q = xor32_sum(q);
-        const float rstd = rsqrtf(fmaxf(q - n_pad * mean * mean, 0.f) * inv_c + p.eps);
-#pragma unroll
-        for (int k = 0; k < NK; ++k) {
-            const f32x4 g0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgam, (32 * k + 8 * g) * 4, 0, 0));
-            const f32x4 g1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgam, (32 * k + 8 * g + 4) * 4, 0, 0));
-            const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbet, (32 * k + 8 * g) * 4, 0, 0));
-            const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbet, (32 * k + 8 * g + 4) * 4, 0, 0));
-            u32x4 o;
-            o[0] = pack_bf16x2(v[k][0] * rstd * g0[0] + b0[0], v[k][1] * rstd * g0[1] + b0[1]);
-            o[1] = pack_bf16x2(v[k][2] * rstd * g0[2] + b0[2], v[k][3] * rstd * g0[3] + b0[3]);
-            o[2] = pack_bf16x2(v[k][4] * rstd * g1[0] + b1[0], v[k][5] * rstd * g1[1] + b1[1]);
-            o[3] = pack_bf16x2(v[k][6] * rstd * g1[2] + b1[2], v[k][7] * rstd * g1[3] + b1[3]);
-            vf[rt][k] = __builtin_bit_cast(bf16x8, o);
-        }
-    }
-    write_slice(0);
-    if (NS > 1) load_slice(1);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    f32x4 y[RT][NCT];
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) y[rt][ct] = zero;
-#pragma unroll 1
-    for (int s = 0; s < NS; ++s) {
-        __syncthreads();          // slice s is visible to everyone, everyone is done with the other slot (slice s - 1)
-        if (s + 1 < NS) write_slice((s + 1) & 1);
-        if (s + 2 < NS) load_slice(s + 2);
-        const u32x4* fr = ring + (s & 1) * NF * 64;
-        f32x4 h[RT][2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const f32x4 bias = *reinterpret_cast<const f32x4*>(&sB1[32 * s + 8 * g + 4 * u]);     // b1[hid(2s + u, 4g + r)]
-#pragma unroll
-            for (int rt = 0; rt < RT; ++rt) h[rt][u] = bias;
-        }
-#pragma unroll
-        for (int k = 0; k < NK; ++k)
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const bf16x8 a = LDS_FRAG(fr, u * NK + k, lane);
-#pragma unroll
-                for (int rt = 0; rt < RT; ++rt) h[rt][u] = MFMA(a, vf[rt][k], h[rt][u]);
-            }
-        bf16x8 hf[RT];
+    const int ngroups = (p.M + 16 * RT - 1) / (16 * RT);
+    // (streamed: exactly one group per wave, grid = ceil(groups / WAVES), so every wave reaches every barrier; a group beyond the end is
+    //  all out-of-range rows: zero loads, dropped stores)
+    auto process = [&](const int grp) {
+        // ---- this wave's 32 tokens: LayerNorm -> B-operand fragments
+        unsigned rbase[RT];
+        float sc[RT];
+        bf16x8 vf[RT][NK];
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
+            const int row = grp * 16 * RT + 16 * rt + i16;
+            const bool ok = row < p.M;
+            rbase[rt] = ok ? (unsigned)row * (unsigned)(C * 2) : OOB_OFF;
+            sc[rt] = (p.scale && ok) ? p.scale[row / p.rows_per_sample] : 1.f;
+            u32x4 xr[NK];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) xr[k] = __builtin_amdgcn_raw_buffer_load_b128(rx, (ok && 32 * k + 8 * g < C) ? rbase[rt] + (32 * k + 8 * g) * 2 : OOB_OFF, 0, 0);
+            float v[NK][8];
+            float sm = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[k][2 * j] = blo(xr[k][j]);
+                    v[k][2 * j + 1] = bhi(xr[k][j]);
+                    sm += v[k][2 * j] + v[k][2 * j + 1];
+                }
+            sm = xor16_sum(sm);
+            sm = xor32_sum(sm);
+            const float mean = sm * inv_c;
+            float q = 0.f;
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    v[k][j] -= mean;
+                    q += v[k][j] * v[k][j];
+                }
+            q = xor16_sum(q);
+            q = xor32_sum(q);
+            const float rstd = rsqrtf(fmaxf(q - n_pad * mean * mean, 0.f) * inv_c + p.eps);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                const f32x4 g0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgam, (32 * k + 8 * g) * 4, 0, 0));
+                const f32x4 g1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rgam, (32 * k + 8 * g + 4) * 4, 0, 0));
+                const f32x4 b0 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbet, (32 * k + 8 * g) * 4, 0, 0));
+                const f32x4 b1 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rbet, (32 * k + 8 * g + 4) * 4, 0, 0));
+                u32x4 o;
+                o[0] = pack_bf16x2(v[k][0] * rstd * g0[0] + b0[0], v[k][1] * rstd * g0[1] + b0[1]);
+                o[1] = pack_bf16x2(v[k][2] * rstd * g0[2] + b0[2], v[k][3] * rstd * g0[3] + b0[3]);
+                o[2] = pack_bf16x2(v[k][4] * rstd * g1[0] + b1[0], v[k][5] * rstd * g1[1] + b1[1]);
+                o[3] = pack_bf16x2(v[k][6] * rstd * g1[2] + b1[2], v[k][7] * rstd * g1[3] + b1[3]);
+                vf[rt][k] = __builtin_bit_cast(bf16x8, o);
+            }
+        }
+        if (!RESIDENT) {
+            write_slice(0);
+            if (NS > 1) load_slice(1);
+        }
+        f32x4 y[RT][NCT];
+#pragma unroll
+        for (int rt = 0; rt < RT; ++rt)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) y[rt][ct] = zero;
+#pragma unroll 1
+        for (int s = 0; s < NS; ++s) {
+            if (!RESIDENT) {
+                __syncthreads();          // slice s is visible to everyone, everyone is done with the other slot (slice s - 1)
+                if (s + 1 < NS) write_slice((s + 1) & 1);
+                if (s + 2 < NS) load_slice(s + 2);
+            }
+            const u32x4* fr = ring + (RESIDENT ? s : (s & 1)) * NF * 64;
+            f32x4 h[RT][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const f32x4 bias = *reinterpret_cast<const f32x4*>(&sB1[32 * s + 8 * g + 4 * u]);     // b1[hid(2s + u, 4g + r)]
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) h[rt][u] = bias;
+            }
+#pragma unroll
+            for (int k = 0; k < NK; ++k)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const bf16x8 a = LDS_FRAG(fr, u * NK + k, lane);
+#pragma unroll
+                    for (int rt = 0; rt < RT; ++rt) h[rt][u] = MFMA(a, vf[rt][k], h[rt][u]);
+                }
+            bf16x8 hf[RT];
+#pragma unroll
+            for (int rt = 0; rt < RT; ++rt) {
 #if PK_MLP_WIDE_GELU_POLY
-            hf[rt] = pack2(gelu_erf_poly(h[rt][0]), gelu_erf_poly(h[rt][1]));          // packed-fp32 polynomial form (pk_common.h)
+                hf[rt] = pack2(gelu_erf_poly(h[rt][0]), gelu_erf_poly(h[rt][1]));          // packed-fp32 polynomial form (pk_common.h)
 #else
-            hf[rt] = pack2(gelu_erf(h[rt][0]), gelu_erf(h[rt][1]));
+                hf[rt] = pack2(gelu_erf(h[rt][0]), gelu_erf(h[rt][1]));
 #endif
+            }
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const bf16x8 a = LDS_FRAG(fr, 2 * NK + ct, lane);
+#pragma unroll
+                for (int rt = 0; rt < RT; ++rt) y[rt][ct] = MFMA(a, hf[rt], y[rt][ct]);
+            }
         }
 #pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const bf16x8 a = LDS_FRAG(fr, 2 * NK + ct, lane);
+        for (int rt = 0; rt < RT; ++rt)
 #pragma unroll
-            for (int rt = 0; rt < RT; ++rt) y[rt][ct] = MFMA(a, hf[rt], y[rt][ct]);
-        }
+            for (int ct = 0; ct < NCT; ++ct) {
+                const unsigned off = rbase[rt] == OOB_OFF ? OOB_OFF : rbase[rt] + (16 * ct + 4 * g) * 2;
+                const u32x2 xo = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
+                const f32x4 b2v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb2, (16 * ct + 4 * g) * 4, 0, 0));
+                const f32x4 o = (y[rt][ct] + b2v) * sc[rt] + unpack4(xo);
+                __builtin_amdgcn_raw_buffer_store_b64(pack4(o), ro, off, 0, 0);
+            }
+    };
+    if (RESIDENT) {
+        for (int grp = blockIdx.x * WAVES + wave; grp < ngroups; grp += gridDim.x * WAVES) process(grp);
+    } else {
+        process(blockIdx.x * WAVES + wave);
     }
-#pragma unroll
-    for (int rt = 0; rt < RT; ++rt)
-#pragma unroll
-        for (int ct = 0; ct < NCT; ++ct) {
-            const unsigned off = rbase[rt] == OOB_OFF ? OOB_OFF : rbase[rt] + (16 * ct + 4 * g) * 2;
-            const u32x2 xo = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
-            const f32x4 b2v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb2, (16 * ct + 4 * g) * 4, 0, 0));
-            const f32x4 o = (y[rt][ct] + b2v) * sc[rt] + unpack4(xo);
-            __builtin_amdgcn_raw_buffer_store_b64(pack4(o), ro, off, 0, 0);
-        }
 }
 
 // ================================================================================================ backward: dx
@@ -965,17 +990,20 @@ __global__ void __launch_bounds__(256) k_attn_fwd(AttnArgs p) {
 // LayerNorm statistics over `c_real` channels (the padded channels of the twin hold zeros), softmax scale = p.softmax_scale (39^-0.5).
 // Forward only (inference): neither the attention output nor the log-sum-exp is saved.  All heads' weight fragments are resident in LDS
 // (C = 80: 74 KB), filled once per workgroup.
-template <int NK, int NCT, int HEADS>
-__global__ void __launch_bounds__(256, 2) k_attn_fwd_w(AttnArgs p, int C, int c_real) {
+template <int NK, int NCT, int HEADS, int WAVES>
+__global__ void __launch_bounds__(64 * WAVES) k_attn_fwd_w(AttnArgs p, int C, int c_real) {
+    constexpr int NT_ = 64 * WAVES;
     constexpr int ET = 3, HDP = 40;
     constexpr int F_QK = 2 * ET * NK, F_V = ET * NK, F_P = NCT, F_HEAD = F_QK + F_V + F_P;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_a[];
     u32x4* sW = reinterpret_cast<u32x4*>(smem_a);                                   // [HEADS][F_HEAD][64]: 16-byte fragments
     u32x2* sP2 = reinterpret_cast<u32x2*>(smem_a + HEADS * F_HEAD * 1024);           // [HEADS][NCT][64]: W_proj columns 32 + 4g .. of the head
     float* sBqkv = reinterpret_cast<float*>(smem_a + HEADS * (F_HEAD * 1024 + NCT * 512));      // [3C]
-    float* sBias = sBqkv + 3 * HEADS * HDP;                                          // [HEADS][176]
+    // rel-pos bias (x log2 e) expanded to the score tiles' accumulator layout, key padding folded in as -inf:
+    // [HEADS][ci][cj][lane] x 4 keys 16cj + 4g + r of query 16ci + (lane & 15)  -- one 16-byte read per score tile
+    f32x4* sBias = reinterpret_cast<f32x4*>(sBqkv + 3 * HEADS * HDP);
     const int tid = threadIdx.x, lane_ = tid & 63, wave = tid >> 6, g_ = lane_ >> 4;
-    for (int idx = tid; idx < HEADS * F_HEAD * 64; idx += 256) {
+    for (int idx = tid; idx < HEADS * F_HEAD * 64; idx += NT_) {
         const int f = idx >> 6, l = idx & 63, i = l & 15, gg = l >> 4, h = f / F_HEAD, fl = f - h * F_HEAD;
         u32x4 v = {0u, 0u, 0u, 0u};
         if (fl < F_QK + F_V) {
@@ -999,23 +1027,23 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_w(AttnArgs p, int C, int c_
         }
         sW[idx] = v;
     }
-    for (int idx = tid; idx < HEADS * NCT * 64; idx += 256) {
+    for (int idx = tid; idx < HEADS * NCT * 64; idx += NT_) {
         const int f = idx >> 6, l = idx & 63, i = l & 15, gg = l >> 4, h = f / NCT, nt = f - h * NCT;
         u32x2 v = {0u, 0u};
         if (gg < 2) v = *reinterpret_cast<const u32x2*>(p.wproj + (size_t)(16 * nt + i) * C + HDP * h + 32 + 4 * gg);
         sP2[idx] = v;
     }
-    for (int i = tid; i < 3 * C; i += 256) sBqkv[i] = p.bqkv[i];
-    for (int i = tid; i < HEADS * 169; i += 256) sBias[(i / 169) * 176 + i % 169] = p.table[(i % 169) * HEADS + i / 169];
-    unsigned ajp[4];                    // bytes r = 0..3: 84 - A(j) for this lane's keys j = 16cj + 4g + r (255: tile padding)
-#pragma unroll
-    for (int cj = 0; cj < 4; ++cj) {
-        ajp[cj] = 0u;
+    for (int i = tid; i < 3 * C; i += NT_) sBqkv[i] = p.bqkv[i];
+    for (int idx = tid; idx < HEADS * 16 * 64; idx += NT_) {
+        const int l = idx & 63, tile = (idx >> 6) & 15, h = idx >> 10, ci = tile >> 2, cj = tile & 3;
+        const int i = 16 * ci + (l & 15), ai = rel_a7(i < AT_N ? i : 0);
+        f32x4 v;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int j = 16 * cj + 4 * g_ + r;
-            ajp[cj] |= (unsigned)(j < AT_N ? 84 - rel_a7(j) : 255) << (8 * r);
+            const int j = 16 * cj + 4 * (l >> 4) + r;
+            v[r] = j < AT_N ? p.table[(ai - rel_a7(j) + 84) * HEADS + h] * 1.44269504088896340736f : -INFINITY;
         }
+        sBias[idx] = v;
     }
     __syncthreads();
     const auto rx = MAKE_RSRC(p.x);
@@ -1025,7 +1053,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_w(AttnArgs p, int C, int c_
     const auto rbp = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.bproj), 0, C * 4, 0x00020000);
     const float inv_c = 1.f / (float)c_real, n_pad = (float)(32 * NK - c_real);
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (int w = blockIdx.x * 4 + wave; w < p.n_windows; w += gridDim.x * 4) {
+    const float qscale = p.softmax_scale * 1.44269504088896340736f;
+    for (int w = blockIdx.x * WAVES + wave; w < p.n_windows; w += gridDim.x * WAVES) {
         const int lane = opaque_lane<true>(lane_), i16 = lane & 15, g = lane >> 4;
         int row[4];
 #pragma unroll
@@ -1149,26 +1178,23 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_w(AttnArgs p, int C, int c_
                     qf = pack2(qa[0], qa[1]);
                     qf2 = __builtin_bit_cast(s16x4, pack4(qa[2]));
                 }
-                const int i = 16 * ci + i16;
-                const int ai = rel_a7(i < AT_N ? i : 0);
                 f32x4 st[4];
+                // Scores and projection as chains of 16-deep MFMAs only (the 32-deep operands are two 16-deep ones side by side in the
+                // same registers, and 3 x 4 passes cost what 8 + 4 do).  NOT a 32-deep MFMA followed by a 16-deep one on its result: hipcc
+                // 7.2 pads nothing between  v_mfma_f32_16x16x32_bf16 D, ..  and a following  v_mfma_f32_16x16x16_bf16 D', .., C = D  with
+                // D' != D, and the second then reads a stale C (seen as 0.5-0.9 relative error whenever the register allocator chose D' != D).
 #pragma unroll
-                for (int cj = 0; cj < 4; ++cj) st[cj] = MFMA(kf[cj], qf, zero);
-                // (separate loops on purpose: hipcc 7.2 does not pad  v_mfma_f32_16x16x32_bf16 D, ..  directly followed by
-                //  v_mfma_f32_16x16x16_bf16 D', .., C = D  with D' != D -- the second reads a stale C; seen as 0.77 relative error in the
-                //  projection below when the two were issued back to back per output tile)
-#pragma unroll
-                for (int cj = 0; cj < 4; ++cj) st[cj] = MFMA16(kf2[cj], qf2, st[cj]);
+                for (int cj = 0; cj < 4; ++cj) {
+                    st[cj] = MFMA16(LO4(kf[cj]), LO4(qf), zero);
+                    st[cj] = MFMA16(HI4(kf[cj]), HI4(qf), st[cj]);
+                    st[cj] = MFMA16(kf2[cj], qf2, st[cj]);
+                }
                 float mx = -INFINITY;
 #pragma unroll
-                for (int cj = 0; cj < 4; ++cj)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int a = (int)((ajp[cj] >> (8 * r)) & 255u);
-                        const float bv = sBias[h * 176 + ai + (a != 255 ? a : 0)];
-                        st[cj][r] = a != 255 ? st[cj][r] * p.softmax_scale + bv : -INFINITY;
-                        mx = fmaxf(mx, st[cj][r]);
-                    }
+                for (int cj = 0; cj < 4; ++cj) {
+                    st[cj] = __builtin_elementwise_fma(st[cj], (f32x4)(qscale), sBias[((h * 4 + ci) * 4 + cj) * 64 + lane]);      // log2 domain
+                    mx = fmaxf(fmaxf(mx, fmaxf(st[cj][0], st[cj][1])), fmaxf(st[cj][2], st[cj][3]));
+                }
                 mx = xor16_max(mx);
                 mx = xor32_max(mx);
                 float sum = 0.f;
@@ -1176,7 +1202,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_w(AttnArgs p, int C, int c_
                 for (int cj = 0; cj < 4; ++cj)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        st[cj][r] = __expf(st[cj][r] - mx);
+                        st[cj][r] = __builtin_amdgcn_exp2f(st[cj][r] - mx);
                         sum += st[cj][r];
                     }
                 sum = xor16_sum(sum);
@@ -1192,10 +1218,12 @@ __global__ void __launch_bounds__(256, 2) k_attn_fwd_w(AttnArgs p, int C, int c_
                 const bf16x8 of0 = pack2(o[0], o[1]);
                 const s16x4 of1 = __builtin_bit_cast(s16x4, pack4(o[2]));
 #pragma unroll
-                for (int nt = 0; nt < NCT; ++nt) accY[ci][nt] = MFMA(LDS_FRAG(hw, F_QK + F_V + nt, lane), of0, accY[ci][nt]);
-#pragma unroll
-                for (int nt = 0; nt < NCT; ++nt)
+                for (int nt = 0; nt < NCT; ++nt) {
+                    const bf16x8 wp = LDS_FRAG(hw, F_QK + F_V + nt, lane);
+                    accY[ci][nt] = MFMA16(LO4(wp), LO4(of0), accY[ci][nt]);
+                    accY[ci][nt] = MFMA16(HI4(wp), HI4(of0), accY[ci][nt]);
                     accY[ci][nt] = MFMA16(__builtin_bit_cast(s16x4, sP2[(h * NCT + nt) * 64 + lane]), of1, accY[ci][nt]);
+                }
             }
         }
 #pragma unroll
@@ -1644,21 +1672,21 @@ extern "C" int pk_attn_block_wide_supported(int C, int heads, int n_windows) {
     if (!(on && C == 80 && heads == 2)) return 0;
     return n_windows <= 0 || n_windows >= min_win;
 }
-template <int NK, int NCT, int HEADS>
+template <int NK, int NCT, int HEADS, int WAVES>
 static int attn_wide_launch(const AttnArgs& a, int C, int c_real, hipStream_t st) {
-    const int lds = HEADS * ((3 * 3 * NK + NCT) * 1024 + NCT * 512) + 3 * C * 4 + HEADS * 176 * 4;
+    const int lds = HEADS * ((3 * 3 * NK + NCT) * 1024 + NCT * 512) + 3 * C * 4 + HEADS * 16 * 1024;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_attn_fwd_w<NK, NCT, HEADS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k_attn_fwd_w<NK, NCT, HEADS, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) {
             pk_set_error("pk_attn_block_wide_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
             return (int)e;
         }
         attr_set = true;
     }
-    static const int cap = getenv("PK_ATTN_WIDE_WGS") ? atoi(getenv("PK_ATTN_WIDE_WGS")) : 512;
-    const int need = (a.n_windows + 3) / 4;
-    hipLaunchKernelGGL((k_attn_fwd_w<NK, NCT, HEADS>), dim3(need < cap ? need : cap), dim3(256), lds, st, a, C, c_real);
+    static const int cap = getenv("PK_ATTN_WIDE_WGS") ? atoi(getenv("PK_ATTN_WIDE_WGS")) : 256;      // one 8-wave workgroup per CU (104 KB of LDS)
+    const int need = (a.n_windows + WAVES - 1) / WAVES;
+    hipLaunchKernelGGL((k_attn_fwd_w<NK, NCT, HEADS, WAVES>), dim3(need < cap ? need : cap), dim3(64 * WAVES), lds, st, a, C, c_real);
     return pk_launch_status("pk_attn_block_wide_fwd");
 }
 extern "C" int pk_attn_block_wide_fwd(const void* x, const int32_t* rowmap, const float* gamma, const float* beta, const float* rel_table,
@@ -1676,7 +1704,7 @@ extern "C" int pk_attn_block_wide_fwd(const void* x, const int32_t* rowmap, cons
     a.x = (const uint16_t*)x; a.out = (uint16_t*)y; a.rowmap = rowmap; a.gamma = gamma; a.beta = beta; a.table = rel_table; a.bqkv = bqkv;
     a.bproj = bproj; a.scale = row_scale; a.wqkv = (const uint16_t*)wqkv; a.wproj = (const uint16_t*)wproj;
     a.n_windows = n_windows; a.windows_per_sample = windows_per_sample > 0 ? windows_per_sample : 1; a.eps = eps; a.softmax_scale = softmax_scale;
-    return attn_wide_launch<3, 5, 2>(a, C, c_real, (hipStream_t)stream);
+    return attn_wide_launch<3, 5, 2, 8>(a, C, c_real, (hipStream_t)stream);
 }
 
 // ================================================================================================ C-ABI
@@ -1731,6 +1759,15 @@ extern "C" int pk_ln_mlp_fwd(const void* x, const float* gamma, const float* bet
     return pk_launch_status("pk_ln_mlp_fwd");
 }
 
+static int pk_cu_count_block() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
+    return n;
+}
 // Wide channels, forward only (inference; training of these widths takes the unfused sequence, whose backward needs the hidden saved).
 // `M` > 0 also asks whether the launch pays: a workgroup walks ALL hidden slices for its 128 / 256 tokens, so a launch with few
 // workgroups is one long serial chain per CU -- measured in cfg 5 (HRFormer-base twin, B = 64 with the flip): C = 320 with 13 824 tokens
@@ -1745,18 +1782,29 @@ extern "C" int pk_ln_mlp_wide_supported(int C, int hidden, int M) {
 }
 template <int NK, int NCT, int WAVES>
 static int mlp_wide_launch(const MlpArgs& a, int C, int c_real, int HD, hipStream_t st) {
-    const int lds = 2 * (2 * NK + NCT) * 1024 + HD * 4;
+    constexpr int NF = 2 * NK + NCT;
+    static const int res_on = getenv("PK_MLP_WIDE_RESIDENT") ? atoi(getenv("PK_MLP_WIDE_RESIDENT")) : 1;
+    const int NS = HD / 32, lds_res = NS * NF * 1024 + HD * 4;
+    const bool resident = res_on && lds_res <= 150 * 1024;         // every slice fits: stage once, persistent workgroups, no per-slice barrier
+    const int lds = resident ? lds_res : 2 * NF * 1024 + HD * 4;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fwd_w<NK, NCT, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (2 * NK + NCT) * 1024 + 2048 * 4);
+        hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fwd_w<NK, NCT, WAVES, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void*)k_mlp_fwd_w<NK, NCT, WAVES, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NF * 1024 + 2048 * 4);
         if (e != hipSuccess) {
             pk_set_error("pk_ln_mlp_wide_fwd: cannot raise the LDS limit: %s", hipGetErrorString(e));
             return (int)e;
         }
         attr_set = true;
     }
-    const dim3 grid((a.M + 32 * WAVES - 1) / (32 * WAVES)), block(64 * WAVES);
-    hipLaunchKernelGGL((k_mlp_fwd_w<NK, NCT, WAVES>), grid, block, lds, st, a, C, c_real, HD);
+    const int need = (a.M + 32 * WAVES - 1) / (32 * WAVES);
+    if (resident) {
+        const int cus = pk_cu_count_block();
+        hipLaunchKernelGGL((k_mlp_fwd_w<NK, NCT, WAVES, true>), dim3(need < cus ? need : cus), dim3(64 * WAVES), lds, st, a, C, c_real, HD);
+    } else {
+        hipLaunchKernelGGL((k_mlp_fwd_w<NK, NCT, WAVES, false>), dim3(need), dim3(64 * WAVES), lds, st, a, C, c_real, HD);
+    }
     return pk_launch_status("pk_ln_mlp_wide_fwd");
 }
 extern "C" int pk_ln_mlp_wide_fwd(const void* x, const float* gamma, const float* beta, const void* w1, const float* b1, const void* w2,

@@ -2,6 +2,7 @@
 """Stand-alone launches for the rocprofv3 --pmc traffic passes (FETCH_SIZE / WRITE_SIZE, one counter per pass).
 
     python3 scripts/prof_kernels.py isolated    the roofline table's GEMM-shaped probes, each kernel name on ONE shape, 3 launches each
+    python3 scripts/prof_kernels.py wide        the forward-only wide fused halves (k_attn_fwd_w, k_mlp_fwd_w) at their cfg-5 shapes
     python3 scripts/prof_kernels.py step        two eager training steps of BASELINE cfg 2 (B = 64): every kernel of the step at its real
                                                 shapes (per-kernel-name means are exact for single-shape kernels: k_reduce_many, k_conv8p,
                                                 k_wgrad3, the C = 32 / 64 fused block kernels, k_adamw)"""
@@ -22,7 +23,22 @@ mode = sys.argv[1] if len(sys.argv) > 1 else "isolated"
 B, H, W = 64, 64, 48
 M = B * H * W
 torch.manual_seed(0)
-if mode == "step":
+if mode == "wide":
+    # the forward-only wide fused halves at their BASELINE cfg 5 shapes (HRFormer-base twin, B = 32: 96 x 72 tokens of C = 80, 48 x 36 of C = 160)
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    for C, heads, Hh, Ww in ((80, 2, 96, 72), (160, 4, 48, 36)):
+        blk = HRFormerBlock(C, heads).to(DEV)
+        blk.c_real, blk.attn_scale = C - 2, float(C // heads - 1) ** -0.5
+        x = (torch.randn(32, Hh, Ww, C, device=DEV) * 1.5).to(BF)
+        a, m = blk.attn, blk.mlp
+        with torch.no_grad(), nnops.use_weights(blk):
+            for _ in range(3):
+                if nnops.wide_attn_enabled(C, heads):
+                    nnops.attn_half_wide_forward(x, blk.norm1.weight, blk.norm1.bias, nnops.rel_table(a, heads), a.qkv.weight, a.qkv.bias, a.proj.weight,
+                                                 a.proj.bias, None, heads, blk.c_real, blk.attn_scale)
+                nnops.mlp_half_wide_forward(x, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias, None, blk.c_real)
+                torch.cuda.synchronize()
+elif mode == "step":
     cfg = get_config("hrformer_small")
     cfg.train.batch_size = B
     model = build_model(cfg).to(DEV)

@@ -42,7 +42,7 @@ CONFIGS = {
                                    "per-GPU batch 32 = the reference's TrainConfig.batch_size default (configs/config.py; its configs/hrnet_w32.yaml is an empty file "
                                    "and BASELINE.json states no batch for this config)"),
     "hrformer_base_infer": dict(preset="preemie", batch=32, mode="infer", metric="images/sec (flip-test inference) HRFormer-B 384x288",
-                                workload="HRFormer-base + fusion head, K=13, 384x288 -> 96x72, flip-test inference (2 forwards + flip merge + decode), "
+                                workload="HRFormer-base + fusion head, K=13, 384x288 -> 96x72, flip-test inference (forward of x and of flip(x) as one 2B-sample batch + flip merge + decode; branch streams inside the graph), "
                                          "8-aligned padded twin"),
 }
 
@@ -341,7 +341,10 @@ class InferRunner:
         if os.environ.get("POSE_GRAPH", "1") != "0":
             try:
                 from infantposeestimation_gaussianbias_amd import dispatch
-                dispatch.set_streams(False)
+                # forward-only fork / join of the branch streams is star-shaped and captures fine (the refused case is backward's
+                # side-stream <-> side-stream edges); branches 2-3 of the wide models are launch-latency-bound and fill the bubbles of
+                # branches 0-1: cfg 5 23.5 -> 19.2 ms.  POSE_INFER_STREAMS=0: one stream.
+                dispatch.set_streams(os.environ.get("POSE_INFER_STREAMS", "1") != "0")
                 s = torch.cuda.Stream()
                 s.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(s), torch.no_grad():

@@ -1,4 +1,5 @@
 """PoseEstimator / build_model: the drop-in surface of the reference's models/pose_estimator.py."""
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -101,11 +102,19 @@ class PoseEstimator(nn.Module):
     @torch.no_grad()
     def inference(self, x, flip: bool = True, flip_pairs: Optional[list] = None):
         """-> keypoints (B,K,2) heat-px, scores (B,K); flip test as pose_estimator.py:275-329 (offsets of the un-flipped pass)."""
-        out = self.forward(x)
-        hm = out["heatmaps"]
-        if flip and flip_pairs is not None:
-            hm_f = self.forward(torch.flip(x, dims=[-1]))["heatmaps"]
-            hm = hipops.flip_merge(hm, hm_f, self._flip_partner(flip_pairs, hm.device))
+        if flip and flip_pairs is not None and not self.training and os.environ.get("POSE_FLIP_BATCHED", "1") != "0":
+            # eval mode: every sample is independent of the rest of its batch (running BatchNorm statistics, per-sample windows), so the two
+            # passes of the flip test are ONE forward over [x ; flip(x)] -- same numbers per sample, half the launches, twice the rows per launch
+            B = x.shape[0]
+            both = self.forward(torch.cat([x, torch.flip(x, dims=[-1])], 0))
+            out = {k: (v[:B] if torch.is_tensor(v) and v.dim() > 0 and v.shape[0] == 2 * B else v) for k, v in both.items()}
+            hm = hipops.flip_merge(out["heatmaps"], both["heatmaps"][B:], self._flip_partner(flip_pairs, x.device))
+        else:
+            out = self.forward(x)
+            hm = out["heatmaps"]
+            if flip and flip_pairs is not None:
+                hm_f = self.forward(torch.flip(x, dims=[-1]))["heatmaps"]
+                hm = hipops.flip_merge(hm, hm_f, self._flip_partner(flip_pairs, hm.device))
         if self.head_type == "fusion":
             o = dict(out)
             o["heatmaps"] = hm

@@ -352,6 +352,51 @@ def test_hrformer_base_eval_forward_vs_golden(golden):
     assert not any("_pk" in k or "twin" in k for k in m.state_dict())
 
 
+@pytest.mark.parametrize("name,K,spec,salt", [("hrformer_base", 13, "hrformer_base_fusion_k13", 44), ("hrformer_small", 17, "hrformer_small_fusion", 40)])
+def test_flip_inference_batched_and_stream_captured_match_two_pass_eager(golden, monkeypatch, name, K, spec, salt):
+    """The serving path of bench.py --config hrformer_base_infer (BASELINE cfg 5; pose_estimator.py:275-329): the flip test as ONE forward
+    over [x ; flip(x)] (eval mode: samples are independent), captured into a hipGraph WITH the concurrent branch streams, against the plain
+    two-pass single-stream eager inference -- key points within 0.05 heat-map px, scores within 1e-2, and the captured graph replays to the
+    same numbers on a second input."""
+    from infantposeestimation_gaussianbias_amd import dispatch
+    from infantposeestimation_gaussianbias_amd.models import PoseEstimator
+    keys = golden("state_keys.json")
+    m = _load(PoseEstimator(name, K, False, "fusion", True), keys[spec], salt).to(DEV).eval()
+    pairs = [(1, 2), (3, 4), (5, 6), (7, 8), (9, 10), (11, 12)]
+    xs = [G(synth_input("flip_a", (3, 3, 128, 96))), G(synth_input("flip_b", (3, 3, 128, 96)))]
+    monkeypatch.setenv("POSE_FUSED_WIDE_FORCE", "1")          # the wide fused halves at these small launches too
+    ref = []
+    monkeypatch.setenv("POSE_FLIP_BATCHED", "0")
+    dispatch.set_streams(False)
+    try:
+        with torch.no_grad():
+            for x in xs:
+                kp, sc = m.inference(x, flip=True, flip_pairs=pairs)
+                ref.append((C(kp), C(sc)))
+        monkeypatch.setenv("POSE_FLIP_BATCHED", "1")
+        dispatch.set_streams(True)
+        with torch.no_grad():
+            kp, sc = m.inference(xs[0], flip=True, flip_pairs=pairs)          # eager, batched, branch streams
+        assert np.abs(C(kp) - ref[0][0]).max() < 0.05 and rel_err(C(sc), ref[0][1]) < 1e-2
+        static = xs[0].clone()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s), torch.no_grad():
+            m.inference(static, flip=True, flip_pairs=pairs)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s):
+                out = m.inference(static, flip=True, flip_pairs=pairs)
+        torch.cuda.current_stream().wait_stream(s)
+        for x, (kp_r, sc_r) in zip(xs, ref):
+            static.copy_(x)
+            g.replay()
+            torch.cuda.synchronize()
+            assert np.abs(C(out[0]) - kp_r).max() < 0.05 and rel_err(C(out[1]), sc_r) < 1e-2
+    finally:
+        dispatch.set_streams(True)
+
+
 def test_hrformer_base_train_step_vs_golden(golden):
     """Train-mode forward + loss + backward of HRFormer-base through the padded twin: losses, the set of grad-less parameters,
     gradient norms (same bf16 bar as HRFormer-small), selected gradient tensors incl. the head-structured qkv/proj weights,

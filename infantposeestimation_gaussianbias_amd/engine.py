@@ -339,7 +339,8 @@ class Trainer:
         if self.comm.world > 1 and overlap_comm:
             self._ms_cb = self._milestone
         # (Measured and dropped for one GPU: running the postponed slab reductions of the finished stages on an auxiliary stream at
-        # the same milestones -- 20.29 -> 20.79 ms per step; the reduction competes with the backward kernels for HBM and queues.)
+        # the same milestones -- 20.29 -> 20.79 ms per step; the reduction competes with the backward kernels for HBM and queues.
+        # Round 3, same experiment on the 17.2 ms step: 17.0-17.4 ms without, 17.5-17.8 ms with, four alternating runs each.)
         # >= 2 eager steps before capture: step 1 installs the gradient sinks, step 2 builds the descriptor tables that depend on
         # them (deferred reductions, padded-twin extraction) -- table uploads are host->device copies and cannot be captured
         self.use_graph, self.graph_warmup = use_graph, max(2, graph_warmup)

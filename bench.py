@@ -320,12 +320,35 @@ def roofline_other(cfg_name, model, B, c):
         sec = time_kernel(lambda: nnops._conv_raw(x, w, C, 3, 1, True))
         return [_entry("k_igemm2<128,32,4,1,32>", f"BasicBlock conv3x3 32->32 @96x72, B={B}, fwd + BN-stat epilogue", "hbm", sec,
                        flops=2.0 * B * H * W * C * 9 * C, bytes_=2.0 * 2 * B * H * W * C)]
-    # HRFormer-base twin: head conv 3x3 256->256 @96x72 (the head dominates: 2 x 4 launches per flip-test pass)
+    # HRFormer-base twin.  The flip test runs x and flip(x) as ONE batch: every launch sees 2B samples.
+    from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
+    B2 = 2 * B
     H, W, C = 96, 72, 256
-    x, w = torch.randn(B, H, W, C, device=dev).to(BF), torch.randn(C, 9, C, device=dev).to(BF)
+    x, w = torch.randn(B2, H, W, C, device=dev).to(BF), torch.randn(C, 9, C, device=dev).to(BF)
     sec = time_kernel(lambda: nnops._conv_raw(x, w, C, 3, 1, False))
-    return [_entry("k_conv8p", f"head conv3x3 256->256 @96x72, B={B}, forward (eval: no statistics)", "mfma", sec, flops=2.0 * B * H * W * C * 9 * C,
-                   bytes_=2.0 * 2 * B * H * W * C)]
+    rows = [_entry("k_conv8p", f"head conv3x3 256->256 @96x72, {B2} samples, forward (eval: no statistics)", "mfma", sec,
+                   flops=2.0 * B2 * H * W * C * 9 * C, bytes_=2.0 * 2 * B2 * H * W * C)]
+    del x, w
+    # the forward-only fused halves of the wide branches (k_attn_fwd_w / k_mlp_fwd_w): algorithmic bytes = x read + y written + the weights once
+    for Cb, heads, Hb, Wb in ((80, 2, 96, 72), (160, 4, 48, 36)):
+        blk = HRFormerBlock(Cb, heads).to(dev).eval()
+        blk.c_real, blk.attn_scale = Cb - 2, float(Cb // heads - 1) ** -0.5
+        xb = (torch.randn(B2, Hb, Wb, Cb, device=dev) * 1.5).to(BF)
+        a, m = blk.attn, blk.mlp
+        M = B2 * Hb * Wb
+        with torch.no_grad(), nnops.use_weights(blk):
+            if nnops.wide_attn_enabled(Cb, heads, B2 * -(-Hb // 7) * -(-Wb // 7)):
+                sec = time_kernel(lambda: nnops.attn_half_wide_forward(xb, blk.norm1.weight, blk.norm1.bias, nnops.rel_table(a, heads), a.qkv.weight,
+                                                                       a.qkv.bias, a.proj.weight, a.proj.bias, None, heads, blk.c_real, blk.attn_scale))
+                rows.append(_entry(f"k_attn_fwd_w (C={Cb})", f"attention half of the block, {M} tokens of C={Cb} ({heads} heads of 40), 7x7 windows", "hbm", sec,
+                                   flops=2.0 * M * Cb * 4 * Cb + 4.0 * M * 49 * Cb, bytes_=2.0 * 2 * M * Cb + 2.0 * 4 * Cb * Cb))
+            if nnops.wide_mlp_enabled(Cb, 4 * Cb, M):
+                sec = time_kernel(lambda: nnops.mlp_half_wide_forward(xb, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
+                                                                      None, blk.c_real))
+                rows.append(_entry(f"k_mlp_fwd_w (C={Cb})", f"MLP half of the block, {M} tokens of C={Cb}, hidden {4 * Cb}", "hbm", sec,
+                                   flops=2.0 * M * Cb * 8 * Cb, bytes_=2.0 * 2 * M * Cb + 2.0 * 8 * Cb * Cb))
+        del blk, xb
+    return rows
 
 
 class InferRunner:

@@ -27,6 +27,27 @@ def test_library_exports_every_declared_symbol():
     assert rc == -1 and b"null pointer" in _lib.lib.pk_last_error_string()
 
 
+def test_wide_fused_half_rules_and_argument_checks():
+    """The forward-only wide fused halves (pk_ln_mlp_wide_fwd / pk_attn_block_wide_fwd): which shapes the library is built for, its
+    "does the launch pay" rule (enough workgroups / windows), and the argument validation -- all host-side, nothing is launched."""
+    from infantposeestimation_gaussianbias_amd import _lib
+    L = _lib.lib
+    for C in (80, 128, 160, 256, 320):
+        assert L.pk_ln_mlp_wide_supported(C, 4 * C, 0) == 1
+    assert L.pk_ln_mlp_wide_supported(64, 256, 0) == 0 and L.pk_ln_mlp_wide_supported(640, 2560, 0) == 0      # narrow: pk_ln_mlp_fwd; 640: unfused
+    assert L.pk_ln_mlp_wide_supported(80, 100, 0) == 0                                                           # hidden % 32
+    assert L.pk_ln_mlp_wide_supported(80, 320, 64 * 96 * 72) == 1 and L.pk_ln_mlp_wide_supported(160, 640, 64 * 48 * 36) == 1
+    assert L.pk_ln_mlp_wide_supported(320, 1280, 32 * 24 * 18) == 0 and L.pk_ln_mlp_wide_supported(128, 512, 64 * 16 * 12) == 0   # too few workgroups
+    assert L.pk_attn_block_wide_supported(80, 2, 0) == 1 and L.pk_attn_block_wide_supported(160, 4, 0) == 0
+    assert L.pk_attn_block_wide_supported(80, 2, 32 * 154) == 1 and L.pk_attn_block_wide_supported(80, 2, 100) == 0
+    rc = L.pk_ln_mlp_wide_fwd(None, None, None, None, None, None, None, None, None, 1, 80, 78, 320, 1, 1e-5, None)
+    assert rc == -1 and b"null pointer" in L.pk_last_error_string()
+    rc = L.pk_ln_mlp_wide_fwd(None, None, None, None, None, None, None, None, None, 1, 96, 96, 384, 1, 1e-5, None)
+    assert rc == -2 and b"built for" in L.pk_last_error_string()
+    rc = L.pk_attn_block_wide_fwd(None, None, None, None, None, None, None, None, None, None, None, 1, 1, 4, 160, 156, 0.16, 1e-5, None)
+    assert rc == -2 and b"built for" in L.pk_last_error_string()
+
+
 def test_ops_refuse_cpu_tensors():
     from infantposeestimation_gaussianbias_amd import _lib, hipops
     with pytest.raises(_lib.PoseKernelError):

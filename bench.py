@@ -321,6 +321,16 @@ def roofline_other(cfg_name, model, B, c):
         return [_entry("k_igemm2<128,32,4,1,32>", f"BasicBlock conv3x3 32->32 @96x72, B={B}, fwd + BN-stat epilogue", "hbm", sec,
                        flops=2.0 * B * H * W * C * 9 * C, bytes_=2.0 * 2 * B * H * W * C)]
     # HRFormer-base twin.  The flip test runs x and flip(x) as ONE batch: every launch sees 2B samples.
+    try:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_wide.json")) as f:
+            wide_pmc = json.load(f)["kernels"]        # L2-miss bytes per launch at these shapes (scripts/gpu_pmc_traffic_wide.sh)
+    except (OSError, KeyError, ValueError):
+        wide_pmc = {}
+
+    def traffic_of(prefix):
+        hit = [v["traffic_bytes"] for k, v in wide_pmc.items() if k.startswith(prefix)]
+        return hit[0] if len(hit) == 1 else None
+
     from infantposeestimation_gaussianbias_amd.models.hrformer import HRFormerBlock
     B2 = 2 * B
     H, W, C = 96, 72, 256
@@ -342,11 +352,13 @@ def roofline_other(cfg_name, model, B, c):
                                                                        a.qkv.bias, a.proj.weight, a.proj.bias, None, heads, blk.c_real, blk.attn_scale))
                 rows.append(_entry(f"k_attn_fwd_w (C={Cb})", f"attention half of the block, {M} tokens of C={Cb} ({heads} heads of 40), 7x7 windows", "hbm", sec,
                                    flops=2.0 * M * Cb * 4 * Cb + 4.0 * M * 49 * Cb, bytes_=2.0 * 2 * M * Cb + 2.0 * 4 * Cb * Cb))
+                rows[-1]["traffic"] = traffic_of("k_attn_fwd_w<")
             if nnops.wide_mlp_enabled(Cb, 4 * Cb, M):
                 sec = time_kernel(lambda: nnops.mlp_half_wide_forward(xb, blk.norm2.weight, blk.norm2.bias, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias,
                                                                       None, blk.c_real))
                 rows.append(_entry(f"k_mlp_fwd_w (C={Cb})", f"MLP half of the block, {M} tokens of C={Cb}, hidden {4 * Cb}", "hbm", sec,
                                    flops=2.0 * M * Cb * 8 * Cb, bytes_=2.0 * 2 * M * Cb + 2.0 * 8 * Cb * Cb))
+                rows[-1]["traffic"] = traffic_of(f"k_mlp_fwd_w<{-(-Cb // 32)}, ")
         del blk, xb
     return rows
 

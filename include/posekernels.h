@@ -151,6 +151,12 @@ int pk_adamw_step(float* param, const float* grad, float* exp_avg, float* exp_av
 int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, float* stats_partial, const float* bias,
                    int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int dilated_input, int Ho, int Wo,
                    int act, int out_mode, const void* addend, void* stream);
+/* conv -> eval-mode BatchNorm (-> + residual) (-> ReLU) as ONE launch (models/hrnet.py:24-52 / :92-102 in eval mode: the running
+ * statistics make the normalisation a per-channel affine map): out = relu?(col_scale[n] * conv(x)[., n] + col_shift[n] + residual),
+ * bf16 NHWC in and out, fp32 scale / shift.  Inference only; ksize 1 / 3, stride 1 / 2. */
+int pk_conv2d_affine_nhwc(const void* x, const void* w_packed, void* out, const float* col_scale, const float* col_shift,
+                          const void* residual, int relu, int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int Ho,
+                          int Wo, void* stream);
 int pk_conv_stats_tiles(int M);
 /* Rows of the [rows][2][Cout] partial-statistics buffer a pk_conv2d_nhwc launch with bf16 output and statistics writes for this geometry
  * (the 3x3 halo kernel emits one row per 64 padded positions; everything else pk_conv_stats_tiles(B*Ho*Wo)).  Replaces the per-call

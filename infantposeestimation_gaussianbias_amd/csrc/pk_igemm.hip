@@ -30,6 +30,7 @@ struct IgemmArgs {
     const uint16_t* w;        // weights bf16 [N][T][Cin]
     void* out;                // see out_mode
     const float* bias;        // [N] or null
+    const float* col_scale;   // [N] or null: the accumulator is multiplied by it before the bias (eval-mode BatchNorm folded into the conv)
     const uint16_t* res;      // residual, same layout as a bf16 row-major output, or null
     const float* res_scale;   // per-sample multiplier of the GEMM result before the residual add, [B] or null
     const int32_t* a_rowmap;  // [M] source row or -1 (linear mode only), or null
@@ -43,7 +44,7 @@ struct IgemmArgs {
     int stride, pad, dilated; // conv geometry
     int ldo;                  // output row pitch in elements (row-major modes)
     int rows_per_sample;      // rows of one sample (for res_scale): Ho*Wo or tokens per image
-    int act;                  // 0 none, 1 GELU(erf), 2 softplus
+    int act;                  // 0 none, 1 GELU(erf), 2 softplus, 3 ReLU applied AFTER the residual add
     int out_mode;             // 0 bf16 row-major, 1 fp32 row-major, 2 fp32 NCHW planes [B][N][Ho*Wo]
     int xcd_remap;            // set by igemm_launch (PK_IGEMM_XCD=0 disables the XCD-contiguous tile order)
     int vec8;                 // set by igemm_launch: row-major pointers 16-byte aligned and ldo % 8 == 0 -> 16-byte epilogue I/O
@@ -82,10 +83,15 @@ __device__ __forceinline__ int fast_div24(int q, int d, float inv) {
 __device__ __forceinline__ float bf16_lo(uint32_t u) { return __uint_as_float(u << 16); }
 __device__ __forceinline__ float bf16_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
 
-__device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo, f32x4 hi, f32x4 blo, f32x4 bhi, int orow, int n,
+__device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo, f32x4 hi, f32x4 slo, f32x4 shi, f32x4 blo, f32x4 bhi, int orow, int n,
                                                     float rs, int hw_out) {
-    lo += blo;                                            // bias of this lane's 8 columns (zeros when absent)
-    hi += bhi;
+    if (p.col_scale) {                                    // per-column scale of this lane's 8 columns, then the bias (zeros when absent)
+        lo = lo * slo + blo;
+        hi = hi * shi + bhi;
+    } else {
+        lo += blo;
+        hi += bhi;
+    }
     float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     const int nv = p.N - n;                               // valid columns of this segment (>= 1)
     const bool vec = p.vec8 && nv >= 8;
@@ -145,6 +151,10 @@ __device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo
                 if (j < nv) v[j] += bf16_to_f32(p.res[base + j]);
         }
     }
+    if (p.act == 3) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = fmaxf(v[j], 0.f);
+    }
     if (p.out_mode == 0) {
         uint16_t* o = reinterpret_cast<uint16_t*>(p.out) + base;
         if (vec) {
@@ -177,6 +187,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     if (LEAN) {                      // LEAN = 2 keeps the GELU epilogues (fc1: GELU + saved pre-activation; fc2 data gradient: x gelu'(z))
         p.stats = nullptr;
         p.out_mode = 0; p.T = 1; p.Ho = 0; p.Wo = 0; p.dilated = 0; p.vec8 = 1; p.chunk_major = 0; p.dil_group = 0;
+        p.col_scale = nullptr;
         if (LEAN == 1) { p.preact = nullptr; p.gelu_of = nullptr; p.act = 0; }
         else if (p.act != 1) p.act = 0;
     }
@@ -581,6 +592,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             if (n + 4 + j < p.N) bhi[j] = p.bias[n + 4 + j];
         }
     }
+    f32x4 slo = {1.f, 1.f, 1.f, 1.f}, shi = {1.f, 1.f, 1.f, 1.f};
+    if (p.col_scale && n_ok) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (n + j < p.N) slo[j] = p.col_scale[n + j];
+            if (n + 4 + j < p.N) shi[j] = p.col_scale[n + 4 + j];
+        }
+    }
     // The staging tile is wave-private: only the lanes of ONE wave exchange data through it, so a wave-level fence orders the writes
     // against the reads (a workgroup barrier made every wave wait for the slowest of four, twice per pass -- these epilogues are
     // most of the run time of the shallow GEMMs).
@@ -613,7 +632,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
                 const float rs = p.res_scale ? p.res_scale[idiv(orow, p.rows_per_sample)] : 1.f;
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc]);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(&stage[ml * EP + lc + 4]);
-                igemm_epilogue_row8(p, lo, hi, blo, bhi, orow, n, rs, hw_out);
+                igemm_epilogue_row8(p, lo, hi, slo, shi, blo, bhi, orow, n, rs, hw_out);
             }
         }
     }
@@ -833,6 +852,21 @@ __global__ void __launch_bounds__(512, 2) k_conv8p(IgemmArgs p) {
     // ---- epilogue: bf16 tile of the wave (128 pixels x 64 channels = 16 KB) through its own LDS slice, 16-byte chunks XOR-swizzled by
     // (pixel & 7); then 128-byte row segments to global, 16 bytes per lane
     uint16_t* stage = c8_smem + wave * 8192;
+    if (p.col_scale) {          // eval-mode BatchNorm folded in: y = relu?(scale * conv + shift); channel = n0 + 64 wn + 16 a + 4 (lane >> 4) + r
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int c = n0 + wn * 64 + a * 16 + (lane >> 4) * 4;
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(p.col_scale + c), sh = *reinterpret_cast<const f32x4*>(p.bias + c);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                acc[a][b] = acc[a][b] * sc + sh;
+                if (p.act == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[a][b][r] = fmaxf(acc[a][b][r], 0.f);
+                }
+            }
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -1087,9 +1121,17 @@ __global__ void __launch_bounds__(256, 2) k_conv3h(IgemmArgs p, int pieces_per_w
                     }
                 }
                 const unsigned off = ok ? (unsigned)(m * COUT + wn * (COUT / 2) + ni * 16 + g * 4) * 2u : OOB_OFF;
+                if (p.col_scale) {          // eval-mode BatchNorm folded in (scale, shift of this lane's four channels: L1-resident)
+                    const int c = wn * (COUT / 2) + ni * 16 + g * 4;
+                    v = v * *reinterpret_cast<const f32x4*>(p.col_scale + c) + *reinterpret_cast<const f32x4*>(p.bias + c);
+                }
                 if (p.res) {
                     const u32x2 rv = __builtin_amdgcn_raw_buffer_load_b64(rr, off, 0, 0);
                     v[0] += bf16_lo(rv[0]); v[1] += bf16_hi(rv[0]); v[2] += bf16_lo(rv[1]); v[3] += bf16_hi(rv[1]);
+                }
+                if (p.act == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
                 }
                 const u32x2 o = {pack_bf16x2(v[0], v[1]), pack_bf16x2(v[2], v[3])};
                 __builtin_amdgcn_raw_buffer_store_b64(o, ro, off, 0, 0);
@@ -1130,8 +1172,9 @@ static inline bool conv3h_takes(const IgemmArgs& a) {
     const bool on = !on_env || atoi(on_env) != 0;
     const long min_tiles = mt_env ? atol(mt_env) : 96;         // (16x12 x 64 samples = 126 tiles: 11.4 us against 15.3 us on k_igemm2)
     if (!(on && a.Ho > 0 && a.T == 9 && a.stride == 1 && !a.dilated && a.Hs == a.Ho && a.Ws == a.Wo && (a.Cin == 32 || a.Cin == 64) &&
-          (a.N == 32 || a.N == 64) && a.out_mode == 0 && !a.bias && !a.res_scale && !a.a_rowmap && !a.o_rowmap && !a.preact && !a.gelu_of &&
-          a.act == 0 && a.ldo == a.N && !(a.res && a.stats)))
+          (a.N == 32 || a.N == 64) && a.out_mode == 0 && (!a.bias || a.col_scale) && !a.res_scale && !a.a_rowmap && !a.o_rowmap && !a.preact &&
+          !a.gelu_of && (a.act == 0 || (a.act == 3 && !a.stats)) && !(a.col_scale && (a.stats || !a.bias || (((uintptr_t)a.col_scale | (uintptr_t)a.bias) & 15))) &&
+          a.ldo == a.N && !(a.res && a.stats)))
         return false;
     const int pp = conv3h_pieces_per_wave(a.Ws, a.Cin);
     if (pp < 3 || pp > 11) return false;                       // the counted vmcnt waits are compiled for 3 .. 11 pieces per wave (W <= ~96 at 64 channels)
@@ -1176,7 +1219,8 @@ static inline bool conv8p_takes(const IgemmArgs& a) {
     const bool on = !on_env || atoi(on_env) != 0;
     const long min_tiles = mt_env ? atol(mt_env) : 256;
     return on && a.Ho > 0 && (a.T == 9 || a.T == 1) && a.stride == 1 && !a.dilated && (a.N % 256) == 0 && (a.Cin % 32) == 0 && a.T * a.Cin >= 576 &&
-           a.out_mode == 0 && !a.bias && !a.res && !a.res_scale && !a.a_rowmap && !a.o_rowmap && !a.preact && !a.gelu_of && a.act == 0 &&
+           a.out_mode == 0 && (!a.bias || a.col_scale) && !a.res && !a.res_scale && !a.a_rowmap && !a.o_rowmap && !a.preact && !a.gelu_of &&
+           (a.act == 0 || (a.act == 3 && !a.stats)) && !(a.col_scale && (a.stats || !a.bias || (((uintptr_t)a.col_scale | (uintptr_t)a.bias) & 15))) &&
            a.ldo == a.N && (((uintptr_t)a.out) & 15) == 0 && (long)((a.M + 255) / 256) * (a.N / 256) >= min_tiles && a.Hs == a.Ho && a.Ws == a.Wo;
 }
 
@@ -1314,6 +1358,31 @@ extern "C" int pk_conv2d_nhwc(const void* x, const void* w_packed, void* out, fl
     PK_REQUIRE(!addend || (out_mode == 0 && !stats_partial), "pk_conv2d_nhwc: an addend needs the bf16 row-major output and no statistics");
     a.res = (const uint16_t*)addend;          // out = conv(x) + addend (same shape, bf16): the skip connection's gradient in a data-gradient launch
     return igemm_launch(a, (hipStream_t)stream, "pk_conv2d_nhwc");
+}
+
+// conv -> eval-mode BatchNorm (-> + residual) (-> ReLU) in ONE launch: y = relu?(col_scale[n] * conv(x)[., n] + col_shift[n] + residual).
+// Inference only (the scale / shift are the constants gamma * rsqrt(running_var + eps), beta - running_mean * that); stride 1 or 2.
+extern "C" int pk_conv2d_affine_nhwc(const void* x, const void* w_packed, void* out, const float* col_scale, const float* col_shift,
+                                     const void* residual, int relu, int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int Ho,
+                                     int Wo, void* stream) {
+    const int M = B * Ho * Wo;
+    int rc = check_common("pk_conv2d_affine_nhwc", x, w_packed, out, M, Cout, Cin, Cout, 0);
+    if (rc) return rc;
+    PK_REQUIRE(col_scale && col_shift, "pk_conv2d_affine_nhwc: null scale / shift");
+    PK_REQUIRE((ksize == 1 || ksize == 3) && (stride == 1 || stride == 2), "pk_conv2d_affine_nhwc: ksize %d stride %d", ksize, stride);
+    PK_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && Ho > 0 && Wo > 0, "pk_conv2d_affine_nhwc: bad geometry");
+    const int pad = ksize / 2;
+    PK_REQUIRE(Ho == (Hs + 2 * pad - ksize) / stride + 1 && Wo == (Ws + 2 * pad - ksize) / stride + 1,
+               "pk_conv2d_affine_nhwc: output %dx%d does not match input %dx%d k=%d s=%d", Ho, Wo, Hs, Ws, ksize, stride);
+    PK_REQUIRE((int64_t)B * Hs * Ws * Cin < 0x3fffffffLL && (int64_t)Cout * ksize * ksize * Cin < 0x3fffffffLL,
+               "pk_conv2d_affine_nhwc: input too large for 32-bit byte offsets");
+    PK_REQUIRE((Cout & 3) == 0, "pk_conv2d_affine_nhwc: Cout=%d must be a multiple of 4", Cout);
+    IgemmArgs a{};
+    a.x = (const uint16_t*)x; a.w = (const uint16_t*)w_packed; a.out = out; a.bias = col_shift; a.col_scale = col_scale;
+    a.M = M; a.N = Cout; a.Cin = Cin; a.T = ksize * ksize; a.Hs = Hs; a.Ws = Ws; a.Ho = Ho; a.Wo = Wo;
+    a.stride = stride; a.pad = pad; a.dilated = 0; a.ldo = Cout; a.rows_per_sample = Ho * Wo;
+    a.act = relu ? 3 : 0; a.out_mode = 0; a.res = (const uint16_t*)residual;
+    return igemm_launch(a, (hipStream_t)stream, "pk_conv2d_affine_nhwc");
 }
 
 extern "C" int pk_conv_stats_tiles(int M) { return (M + STAT_ROWS - 1) / STAT_ROWS; }

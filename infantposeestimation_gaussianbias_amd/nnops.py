@@ -413,9 +413,23 @@ class SkipGrad:
         self.g = None
 
 
+def _bn_eval_affine(wc, bn, gamma, beta):
+    """-> (scale, shift, mean, rstd) of an eval-mode BatchNorm: constants of the parameters and the running statistics, computed once
+    (4 small ATen launches) and kept in the weight cache until one of them changes."""
+    key = (gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version, bn.running_mean.data_ptr(), bn.running_mean._version,
+           bn.running_var.data_ptr(), bn.running_var._version)
+    ent = wc.bn_eval.get(id(bn))
+    if ent is None or ent[0] != key:
+        rstd = torch.rsqrt(bn.running_var + 1e-5)
+        scale = gamma * rstd
+        shift = torch.addcmul(beta, bn.running_mean, scale, value=-1.0)
+        ent = wc.bn_eval[id(bn)] = (key, scale.float().contiguous(), shift.float().contiguous(), bn.running_mean.clone(), rstd)
+    return ent[1:]
+
+
 class _ConvBnAct(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, relu, training, skip_out=None, skip_in=None):
+    def forward(ctx, x, weight, gamma, beta, residual, bn, stride, relu, training, skip_out=None, skip_in=None, infer=False):
         ctx.params = (weight, gamma, beta)
         ctx.skip_out, ctx.skip_in = skip_out, skip_in      # skip_out: store d(residual) there; skip_in: add what was stored to dx
         wc = _wc()
@@ -425,11 +439,18 @@ class _ConvBnAct(torch.autograd.Function):
         B, Hs, Ws, Cin, Ho, Wo = _conv_geometry(x, ksize, stride)
         M = B * Ho * Wo
         dev = x.device
+        res = None if residual is None else residual.contiguous()
+        if infer and not training and os.environ.get("POSE_FUSED_EVAL_BN", "1") != "0":
+            # inference: the running statistics make BatchNorm a per-channel affine map -> applied (with the residual and the ReLU) in the
+            # conv's epilogue: ONE launch, the pre-normalisation tensor never exists (pk_conv2d_affine_nhwc)
+            scale, shift = _bn_eval_affine(wc, bn, gamma, beta)[:2]
+            y = _e((B, Ho, Wo, Cout), BF16, dev)
+            call("pk_conv2d_affine_nhwc", x, wf, y, scale, shift, res, 1 if relu else 0, B, Hs, Ws, Cin, Cout, ksize, stride, Ho, Wo, stream_ptr())
+            return y
         raw, part = _conv_raw(x, wf, Cout, ksize, stride, training)
         scale, shift = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
         mean, rstd = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
         y = _e(raw.shape, BF16, dev)
-        res = None if residual is None else residual.contiguous()
         if training:
             wc.bn_eval.pop(id(bn), None)        # the kernel below rewrites the running statistics in place (no version bump)
             # finalize + apply: one fused launch for small tensors, two kernels otherwise (the library decides)
@@ -438,17 +459,7 @@ class _ConvBnAct(torch.autograd.Function):
         else:
             # eval: scale / shift are constants of the parameters -- computed once (4 small ATen launches) and kept until the weights or
             # the statistics change (was: 4 launches per BatchNorm layer and forward, 320 per HRFormer-base inference step)
-            key = (gamma.data_ptr(), gamma._version, beta.data_ptr(), beta._version, bn.running_mean.data_ptr(), bn.running_mean._version,
-                   bn.running_var.data_ptr(), bn.running_var._version)
-            ent = wc.bn_eval.get(id(bn))
-            if ent is None or ent[0] != key:
-                torch.rsqrt(bn.running_var + 1e-5, out=rstd)
-                torch.mul(gamma, rstd, out=scale)
-                torch.addcmul(beta, bn.running_mean, scale, value=-1.0, out=shift)
-                mean.copy_(bn.running_mean)
-                wc.bn_eval[id(bn)] = (key, scale, shift, mean, rstd)
-            else:
-                _, scale, shift, mean, rstd = ent
+            scale, shift, mean, rstd = _bn_eval_affine(wc, bn, gamma, beta)
             call("pk_bn_act", raw, scale, shift, res, y, M, Cout, 1 if relu else 0, stream_ptr())
         ctx.save_for_backward(x, raw, y, mean, rstd, gamma, wd)
         ctx.meta = (stride, relu, training, residual is not None, Cin_real, ksize, (B, Hs, Ws, Ho, Wo))
@@ -487,11 +498,13 @@ class _ConvBnAct(torch.autograd.Function):
             dst, sw = _sink(w_p)
             dw = _wgrad(x, draw, Cout, Cin, ksize, stride, (B, Hs, Ws, Ho, Wo), out=dst, deferred=sw)
             dw = None if sw else dw
-        return dx, dw, None if sg else dgamma, None if sb else dbeta, dres, None, None, None, None, None, None
+        return dx, dw, None if sg else dgamma, None if sb else dbeta, dres, None, None, None, None, None, None, None
 
 
 def conv_bn_act(x, conv, bn, relu=False, residual=None, training=False, skip_out=None, skip_in=None):
-    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], relu, training, skip_out, skip_in)
+    # (grad mode is always off INSIDE an autograd Function's forward: whether nothing will be differentiated is decided here)
+    return _ConvBnAct.apply(x, conv.weight, bn.weight, bn.bias, residual, bn, conv.stride[0], relu, training, skip_out, skip_in,
+                            not torch.is_grad_enabled())
 
 
 def residual_block(x, first, middle, last, training):

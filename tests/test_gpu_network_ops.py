@@ -281,6 +281,46 @@ def test_conv_bn_act_function(N, train, relu, res):
         assert int(m.b.num_batches_tracked) == 1
 
 
+@pytest.mark.parametrize("Cin,Cout,k,stride,B,H,W,relu,res", [
+    (64, 64, 3, 1, 4, 32, 24, True, True),       # k_conv3h (halo kernel): BasicBlock conv2 + skip
+    (32, 32, 3, 1, 3, 48, 36, True, False),      # k_conv3h
+    (256, 256, 3, 1, 2, 16, 12, True, False),    # k_conv8p (head conv; tile floor lowered below)
+    (64, 256, 1, 1, 2, 24, 18, False, True),     # k_igemm2, Bottleneck conv3 + skip
+    (32, 64, 3, 2, 3, 17, 13, False, False),     # k_igemm2, stride-2 exchange conv, odd size
+    (8, 64, 3, 2, 2, 32, 24, True, False),       # stem (3 real input channels in 8-channel pixels)
+    (128, 40, 1, 1, 2, 9, 7, True, True)])       # ragged column tile
+def test_eval_conv_bn_fused_epilogue_vs_torch_and_unfused(N, monkeypatch, Cin, Cout, k, stride, B, H, W, relu, res):
+    """pk_conv2d_affine_nhwc (eval mode: conv -> BatchNorm with running statistics -> + residual -> ReLU in the conv kernel's epilogue, all
+    three conv kernels) against fp32 PyTorch (8e-3: one bf16 store) and against the unfused conv + pk_bn_act pair (1.2e-2: that one rounds
+    the convolution to bf16 before normalising)."""
+    torch.manual_seed(Cin + Cout)
+    conv, bn = torch.nn.Conv2d(Cin, Cout, k, stride, k // 2, bias=False), torch.nn.BatchNorm2d(Cout)
+    with torch.no_grad():
+        conv.weight.copy_(q(conv.weight * 2))
+        bn.weight.copy_(torch.rand(Cout) + 0.5)
+        bn.bias.copy_(torch.randn(Cout) * 0.2)
+        bn.running_mean.copy_(torch.randn(Cout) * 0.1)
+        bn.running_var.copy_(torch.rand(Cout) + 0.5)
+    x = rnd(B, Cin, H, W, seed=6)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    r = rnd(B, Cout, Ho, Wo, seed=7)
+    with torch.no_grad():
+        y_ref = bn.eval()(conv(x))
+        y_ref = y_ref + r if res else y_ref
+        y_ref = torch.relu(y_ref) if relu else y_ref
+    m = Holder(c=conv, b=bn).to(DEV).eval()
+    monkeypatch.setenv("PK_CONV8P_MIN_TILES", "1")
+    monkeypatch.setenv("PK_CONV3H_MIN_TILES", "1")
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("POSE_FUSED_EVAL_BN", fused)
+        with torch.no_grad(), N.use_weights(m):
+            out[fused] = nchw(N.conv_bn_act(nhwc(x), m.c, m.b, relu, nhwc(r) if res else None, False))
+    torch.cuda.synchronize()
+    print("eval conv+bn fused vs fp32", err(out["1"], y_ref), "vs unfused", err(out["1"], out["0"]))
+    assert err(out["1"], y_ref) < 8e-3 and err(out["1"], out["0"]) < 1.2e-2
+
+
 # ------------------------------------------------------------------------------------------------ LayerNorm / linear
 @pytest.mark.parametrize("C_", [32, 64, 128, 256, 24, 16, 8])
 def test_layernorm_fwd_bwd(N, C_):

@@ -83,7 +83,11 @@ class Holder(torch.nn.Module):
                                                 # stride-2 data gradients large enough that whole 128-row tiles lie in ONE parity class (the K loop
                                                 # then walks that class's 1 / 2 / 2 / 4 taps only): even and odd map sizes, N <= 32 with a deep
                                                 # contraction (the shape that also qualifies for the chunk-major order of stride-1 convs)
-                                                (4, 32, 24, 32, 32, 3, 2), (4, 32, 24, 32, 128, 3, 2), (3, 33, 27, 64, 64, 3, 2), (2, 64, 48, 64, 256, 3, 2)])
+                                                (4, 32, 24, 32, 32, 3, 2), (4, 32, 24, 32, 128, 3, 2), (3, 33, 27, 64, 64, 3, 2), (2, 64, 48, 64, 256, 3, 2),
+                                                # deep contractions on few workgroups (low-resolution branches of HRNet-W32): 18 - 36 K-steps on
+                                                # 27 - 430 row tiles, forward and data gradient, ragged rows and columns, stride 2, a deep 1x1
+                                                (4, 12, 9, 256, 256, 3, 1), (3, 24, 18, 128, 128, 3, 1), (2, 13, 11, 128, 136, 3, 1), (5, 24, 18, 128, 256, 3, 2),
+                                                (32, 24, 18, 128, 128, 3, 1), (2, 9, 7, 1024, 96, 1, 1)])
 def test_conv_fwd_dgrad_wgrad(N, B, H, W, Cin, Cout, k, s):
     from infantposeestimation_gaussianbias_amd._lib import call, lib, stream_ptr
     conv = torch.nn.Conv2d(Cin, Cout, k, s, k // 2, bias=False)

@@ -8,6 +8,12 @@ import ctypes
 import os
 import re
 
+# PyTorch's wheel carries its own libamdhip64.so; libposekernels.so is linked against the SONAME only.  Whichever is loaded first
+# serves both: with torch first there is ONE HIP runtime in the process (the one that owns torch's device context and streams).
+# The other order loads /opt/rocm's copy for the kernels and torch's for everything else, and every launch then fails with
+# "no ROCm-capable device is detected" (seen with build() + smoke() in one process).
+import torch  # noqa: F401  (must precede the CDLL below)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # POSE_KERNELS_LIB: another build of the same library (A/B measurements of two builds on one box); it must export every declared symbol
 LIB_PATH = os.environ.get("POSE_KERNELS_LIB") or os.path.join(_HERE, "csrc", "libposekernels.so")

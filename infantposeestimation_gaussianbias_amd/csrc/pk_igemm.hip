@@ -345,6 +345,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     u32x4 ra[A_PT], rb[B_PT], ra2[DEEP ? A_PT : 1], rb2[DEEP ? B_PT : 1];
     auto dma_tiles = [&](int buf, int t, int c0) {       // global -> LDS without registers (DMA variant only)
 #if defined(__HIP_DEVICE_COMPILE__)    // the builtin needs a gfx950 target feature: the host pass of hipcc must not see it
+        c0 = __builtin_amdgcn_readfirstlane(c0);
+        t = __builtin_amdgcn_readfirstlane(t);
         const bool c_ok = (c0 + kcg * 8) < p.Cin;
 #pragma unroll
         for (int i = 0; i < A_PT; ++i)
@@ -357,6 +359,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
 #endif
     };
     auto load_tiles = [&](u32x4* ra, u32x4* rb, int t, int c0) {       // c0: first channel of this K-chunk (wave-uniform)
+        c0 = __builtin_amdgcn_readfirstlane(c0);        // scalar offset operands of the loads below: SGPRs, not a waterfall loop per load
+        t = __builtin_amdgcn_readfirstlane(t);
         const bool c_ok = (c0 + kcg * 8) < p.Cin;
 #pragma unroll
         for (int i = 0; i < A_PT; ++i)
@@ -384,25 +388,32 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
 #pragma unroll
         for (int b = 0; b < MI; ++b) acc[a][b] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int t_next = t_first, c_next = 0;     // (tap, chunk) of the tile being loaded
+    int t_next = __builtin_amdgcn_readfirstlane(t_first), c_next = 0;     // (tap, chunk) of the tile being loaded
     // (Measured and dropped: chunk-major order -- all nine taps of one channel chunk back to back, so that the shifted re-reads of the
     // same pixels stay in L2 instead of cycling ~11 MB per XCD between two taps (PMC: the head conv fetches 4.1x its input).  The row
     // offsets must then be recomputed every step: head conv forward 335 -> 400 us, dgrad 290 -> 360 us; only N = 32 tiles gained.)
     // ... kept for BN = 32 with nine taps and >= 128 input channels (p.chunk_major, set by igemm_launch): 3x3 256 -> 32 @64x48 fetched
     // 681 MB for its 100 MB input at 5.8 TB/s of fabric traffic, 118 us.)
+    // (tap, chunk) are the same for every lane, but the compiler's divergence analysis loses that across the lambdas: it kept c_next in a
+    // VGPR, compared it with VALU instructions and -- since it is the scalar offset operand of every staging load -- wrapped EACH buffer load
+    // of the K loop in a waterfall loop (v_readfirstlane / v_cmp_eq / s_and_saveexec / load / branch).  An explicit readfirstlane after every
+    // update makes them SGPR values again: scalar compares, scalar branches, plain loads.
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
     auto advance = [&]() {                // next (tap, chunk) in contraction order; recomputes the row offsets on a tap change
         if (BN == 32 && p.chunk_major) {
             if (++t_next == p.T) {
                 t_next = 0;
                 c_next += BK;
             }
+            t_next = uni(t_next);
+            c_next = uni(c_next);
             set_tap(t_next);
             return;
         }
-        c_next += BK;
+        c_next = uni(c_next + BK);
         if (c_next >= p.Cin) {
             c_next = 0;
-            t_next = next_tap(t_next);
+            t_next = uni(next_tap(t_next));
             set_tap(t_next);
         }
     };

@@ -184,7 +184,13 @@ __device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo
 template <int BM, int BN, int WM, int WN, int BK, int LEAN = 0>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_igemm2(IgemmArgs p_in) {
     IgemmArgs p = p_in;
-    if (LEAN) {                      // LEAN = 2 keeps the GELU epilogues (fc1: GELU + saved pre-activation; fc2 data gradient: x gelu'(z))
+    if (LEAN == 3) {
+        // every feature of the epilogue, but the PLAIN addressing in the K loop: no dilated gather (stride-2 data gradients), no parity
+        // grouping, no chunk-major order.  The generic loop body is 681 instructions around 8 MFMAs on the 128 x 32 tile (295 VALU, 360 SALU,
+        // 52 branches: the run-time flags of those three modes are tested in every advance / set_tap) -- ~0.8 us per K-step whatever the
+        // tile does, which is what bounds the deep contractions of the low-resolution branches.  With the flags constant the compiler drops it.
+        p.dilated = 0; p.chunk_major = 0; p.dil_group = 0;
+    } else if (LEAN) {               // LEAN = 2 keeps the GELU epilogues (fc1: GELU + saved pre-activation; fc2 data gradient: x gelu'(z))
         p.stats = nullptr;
         p.out_mode = 0; p.T = 1; p.Ho = 0; p.Wo = 0; p.dilated = 0; p.vec8 = 1; p.chunk_major = 0; p.dil_group = 0;
         p.col_scale = nullptr;
@@ -1259,6 +1265,12 @@ static void igemm_log_add(const IgemmArgs& a) {
              a.gelu_of != nullptr, a.out_mode);
     igemm_log()[buf]++;
 }
+// plain launches (no dilated gather, no chunk-major order) take the LEAN = 3 instantiation of the same tile: see the kernel's first lines
+#define IGEMM_GO(BM_, BN_, WM_, WN_, BK_, GRID)                                                                      \
+    do {                                                                                                             \
+        if (plain) hipLaunchKernelGGL((k_igemm2<BM_, BN_, WM_, WN_, BK_, 3>), GRID, block, 0, st, a);                \
+        else hipLaunchKernelGGL((k_igemm2<BM_, BN_, WM_, WN_, BK_>), GRID, block, 0, st, a);                         \
+    } while (0)
 static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) {
     IgemmArgs a = a_in;
     igemm_log_add(a);
@@ -1276,6 +1288,8 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
         return pk_launch_status(who);
     }
     const dim3 block(256);
+    static const int plain_on = getenv("PK_IGEMM_PLAIN") ? atoi(getenv("PK_IGEMM_PLAIN")) : 1;
+    const bool plain = plain_on && !a.dilated && !a.chunk_major;
     const unsigned gm = (unsigned)((a.M + 127) / 128);
     // Deep contractions with wide outputs (the 3x3 convs of the head: K = 2304, N = 128/256): 256 x 128 workgroup tile, 128 x 64
     // per wave -- a third less LDS traffic per MFMA than the 64 x 64 wave tile, which is what bounds those kernels.
@@ -1283,7 +1297,7 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     // (needs >= 1024 workgroups: with 768 -- N = 128 at M = 196 608 -- the second round of workgroups is half empty and the
     // kernel is slower than the 128 x 128 tile.  Measured at N = 256: fwd 361 -> 334 us, dgrad 306 -> 285 us.)
     if (big_on && (a.N % 128) == 0 && a.T * a.Cin >= 576 && (a.Cin % 32) == 0 && (long)((a.M + 255) / 256) * (a.N / 128) >= 1024) {
-        hipLaunchKernelGGL((k_igemm2<256, 128, 2, 2, 32>), dim3((a.M + 255) / 256, a.N / 128), block, 0, st, a);
+        IGEMM_GO(256, 128, 2, 2, 32, dim3((a.M + 255) / 256, a.N / 128));
         return pk_launch_status(who);
     }
     // deeper K-chunks when the channel count allows full 64-wide tiles -- except for contractions of <= 128 (one or two steps): the BK = 32
@@ -1305,24 +1319,24 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     if (small_m && (long)gm * ((a.N + 63) / 64) < 512 && !a.stats) {
         if (lean) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64, 1>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
         else if (lean_g) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64, 2>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
-        else if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 32>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
+        else if (k64) IGEMM_GO(128, 32, 4, 1, 64, dim3(gm, (a.N + 31) / 32));
+        else IGEMM_GO(128, 32, 4, 1, 32, dim3(gm, (a.N + 31) / 32));
     } else if (a.N > 64 && (a.T * a.Cin <= 256 || small_m) && (!a.stats || a.T * a.Cin <= 256)) {       // (shallow convs with statistics too: 1x1 64 -> 256 forward 57 -> 47.6 us)
         if (lean) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 1>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
         else if (lean_g) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 2>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
-        else if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 32>), dim3(gm, (a.N + 63) / 64), block, 0, st, a);
+        else if (k64) IGEMM_GO(128, 64, 4, 1, 64, dim3(gm, (a.N + 63) / 64));
+        else IGEMM_GO(128, 64, 4, 1, 32, dim3(gm, (a.N + 63) / 64));
     } else if (a.N > 64) {
-        if (k64) hipLaunchKernelGGL((k_igemm2<128, 128, 2, 2, 64>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<128, 128, 2, 2, 32>), dim3(gm, (a.N + 127) / 128), block, 0, st, a);
+        if (k64) IGEMM_GO(128, 128, 2, 2, 64, dim3(gm, (a.N + 127) / 128));
+        else IGEMM_GO(128, 128, 2, 2, 32, dim3(gm, (a.N + 127) / 128));
     } else if (a.N > 32) {
         if (lean) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 1>), dim3(gm, 1), block, 0, st, a);
         else if (lean_g) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64, 2>), dim3(gm, 1), block, 0, st, a);
-        else if (k64) hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<128, 64, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
+        else if (k64) IGEMM_GO(128, 64, 4, 1, 64, dim3(gm, 1));
+        else IGEMM_GO(128, 64, 4, 1, 32, dim3(gm, 1));
     } else {
-        if (k64) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64>), dim3(gm, 1), block, 0, st, a);
-        else hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 32>), dim3(gm, 1), block, 0, st, a);
+        if (k64) IGEMM_GO(128, 32, 4, 1, 64, dim3(gm, 1));
+        else IGEMM_GO(128, 32, 4, 1, 32, dim3(gm, 1));
     }
     return pk_launch_status(who);
 }

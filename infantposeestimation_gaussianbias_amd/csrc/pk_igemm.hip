@@ -190,6 +190,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         // 52 branches: the run-time flags of those three modes are tested in every advance / set_tap) -- ~0.8 us per K-step whatever the
         // tile does, which is what bounds the deep contractions of the low-resolution branches.  With the flags constant the compiler drops it.
         p.dilated = 0; p.chunk_major = 0; p.dil_group = 0;
+    } else if (LEAN == 4) {          // the stride-2 data gradients (dilated gather, grouped or not): no chunk-major order
+        p.dilated = 1; p.chunk_major = 0;
     } else if (LEAN) {               // LEAN = 2 keeps the GELU epilogues (fc1: GELU + saved pre-activation; fc2 data gradient: x gelu'(z))
         p.stats = nullptr;
         p.out_mode = 0; p.T = 1; p.Ho = 0; p.Wo = 0; p.dilated = 0; p.vec8 = 1; p.chunk_major = 0; p.dil_group = 0;
@@ -302,6 +304,27 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             }
         }
     }
+    // Plain convolutions (LEAN = 3): per staged row ONE signed byte offset of its (virtual) top-left tap and a 9-bit mask of the taps that
+    // fall inside the image; a tap change is then a scalar delta + bit test + select per row instead of re-deriving and bounds-checking
+    // (iy, ix) with divergent branches (~35 instructions per row, on every K-step for 64-channel inputs).
+    int a_off0[A_PT];
+    unsigned a_tmask[A_PT];
+    if (LEAN == 3 && !linear) {
+#pragma unroll
+        for (int i = 0; i < A_PT; ++i) {
+            a_off0[i] = (a_base[i] + (a_iy[i] * p.Ws + a_ix[i]) * p.Cin + kcg * 8) * 2;
+            unsigned mk = 0u;
+            if (a_ok[i]) {
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        if (kh < kw_n && kw < kw_n && a_iy[i] + kh >= 0 && a_iy[i] + kh < p.Hs && a_ix[i] + kw >= 0 && a_ix[i] + kw < p.Ws)
+                            mk |= 1u << (kh * kw_n + kw);
+            }
+            a_tmask[i] = mk;
+        }
+    }
     unsigned b_off[B_PT];
 #pragma unroll
     for (int i = 0; i < B_PT; ++i) {
@@ -320,6 +343,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
 
     unsigned a_voff[A_PT];           // byte offset of (row, current tap, channel kc*8), or OOB
     auto set_tap = [&](int t) {
+        if (LEAN == 3 && !linear) {
+            const int kh3 = kw_n == 3 ? (t * 11) >> 5 : 0, kw3 = t - kh3 * kw_n;          // t / 3 for t < 9
+            const int delta = (kh3 * p.Ws + kw3) * p.Cin * 2;
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) a_voff[i] = ((a_tmask[i] >> t) & 1u) ? (unsigned)(a_off0[i] + delta) : OOB_OFF;
+            return;
+        }
         const int kh = t / kw_n, kw = t - kh * kw_n;
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
@@ -1269,6 +1299,7 @@ static void igemm_log_add(const IgemmArgs& a) {
 #define IGEMM_GO(BM_, BN_, WM_, WN_, BK_, GRID)                                                                      \
     do {                                                                                                             \
         if (plain) hipLaunchKernelGGL((k_igemm2<BM_, BN_, WM_, WN_, BK_, 3>), GRID, block, 0, st, a);                \
+        else if (plain_on && a.dilated && !a.chunk_major) hipLaunchKernelGGL((k_igemm2<BM_, BN_, WM_, WN_, BK_, 4>), GRID, block, 0, st, a);       \
         else hipLaunchKernelGGL((k_igemm2<BM_, BN_, WM_, WN_, BK_>), GRID, block, 0, st, a);                         \
     } while (0)
 static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) {

@@ -350,26 +350,20 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             for (int i = 0; i < A_PT; ++i) a_voff[i] = ((a_tmask[i] >> t) & 1u) ? (unsigned)(a_off0[i] + delta) : OOB_OFF;
             return;
         }
-        const int kh = t / kw_n, kw = t - kh * kw_n;
+        const int kh = kw_n == 3 ? (t * 11) >> 5 : 0, kw = t - kh * kw_n;          // t / 3 for t < 9 (no integer division in the loop)
+        if (linear) {
+#pragma unroll
+            for (int i = 0; i < A_PT; ++i) a_voff[i] = a_ok[i] ? (unsigned)((a_base[i] + kcg * 8) * 2) : OOB_OFF;
+            return;
+        }
+        // branch-free per row (the nested ifs compiled to a divergent branch pair per row and condition: ~35 instructions per row)
+        const int dsh = p.dilated ? 1 : 0;
 #pragma unroll
         for (int i = 0; i < A_PT; ++i) {
-            unsigned off = OOB_OFF;
-            if (a_ok[i]) {
-                if (linear) {
-                    off = (unsigned)((a_base[i] + kcg * 8) * 2);
-                } else {
-                    int iy = a_iy[i] + kh, ix = a_ix[i] + kw;
-                    bool ok = true;
-                    if (p.dilated) {
-                        ok = ((iy | ix) & 1) == 0;
-                        iy >>= 1;
-                        ix >>= 1;
-                    }
-                    if (ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws)
-                        off = (unsigned)((a_base[i] + (iy * p.Ws + ix) * p.Cin + kcg * 8) * 2);
-                }
-            }
-            a_voff[i] = off;
+            const int sy = a_iy[i] + kh, sx = a_ix[i] + kw;
+            const int iy = sy >> dsh, ix = sx >> dsh;
+            const bool ok = a_ok[i] & ((((sy | sx) & dsh) == 0)) & ((unsigned)iy < (unsigned)p.Hs) & ((unsigned)ix < (unsigned)p.Ws);
+            a_voff[i] = ok ? (unsigned)((a_base[i] + (iy * p.Ws + ix) * p.Cin + kcg * 8) * 2) : OOB_OFF;
         }
     };
     constexpr bool DEEP = (BN >= 128 && BK == 64 && !DMA);    // global loads issued TWO tiles ahead (second register set), see the main loop

@@ -208,7 +208,7 @@ def roofline_table(model, B, trainer=None):
         w1 = torch.randn(256, 1, 64, device=dev).to(BF)
         sec = time_kernel(lambda: nnops._conv_raw(x64, w1, 256, 1, 1, False))
         E("k_igemm2<128,64,4,1,32>", "conv1x1 64->256 @64x48 (output-bound: 25 MB in, 100 MB out)", "hbm", sec, flops=2.0 * M * 256 * 64,
-          bytes_=2.0 * (M * 64 + M * 256), trace="k_igemm2<128, 64, 4, 1, 32, 0>(IgemmArgs)")
+          bytes_=2.0 * (M * 64 + M * 256), trace="k_igemm2<128, 64, 4, 1, 32, 3>(IgemmArgs)")      # plain-addressing instantiation (LEAN = 3)
         # 4c. stride-2 data gradient (parity-grouped tap walk): stem conv2 64->64 s2, dx at 128x96
         g2 = torch.randn(B, H, W, 64, device=dev).to(BF)
         wd2 = torch.randn(64, 9, 64, device=dev).to(BF)
@@ -318,7 +318,7 @@ def roofline_other(cfg_name, model, B, c):
         H, W, C = 96, 72, 32
         x, w = torch.randn(B, H, W, C, device=dev).to(BF), torch.randn(C, 9, C, device=dev).to(BF)
         sec = time_kernel(lambda: nnops._conv_raw(x, w, C, 3, 1, True))
-        return [_entry("k_igemm2<128,32,4,1,32>", f"BasicBlock conv3x3 32->32 @96x72, B={B}, fwd + BN-stat epilogue", "hbm", sec,
+        return [_entry("k_conv3h<32,32>", f"BasicBlock conv3x3 32->32 @96x72, B={B}, fwd + BN-stat epilogue", "hbm", sec,
                        flops=2.0 * B * H * W * C * 9 * C, bytes_=2.0 * 2 * B * H * W * C)]
     # HRFormer-base twin.  The flip test runs x and flip(x) as ONE batch: every launch sees 2B samples.
     try:

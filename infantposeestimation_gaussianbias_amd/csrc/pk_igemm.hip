@@ -189,7 +189,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
         // grouping, no chunk-major order.  The generic loop body is 681 instructions around 8 MFMAs on the 128 x 32 tile (295 VALU, 360 SALU,
         // 52 branches: the run-time flags of those three modes are tested in every advance / set_tap) -- ~0.8 us per K-step whatever the
         // tile does, which is what bounds the deep contractions of the low-resolution branches.  With the flags constant the compiler drops it.
-        p.dilated = 0; p.chunk_major = 0; p.dil_group = 0;
+        p.dilated = 0; p.dil_group = 0;       // (chunk-major stays a run-time flag of the 128 x 32 tiles: with the mask form a tap change per step is cheap)
     } else if (LEAN == 4) {          // the stride-2 data gradients (dilated gather, grouped or not): no chunk-major order
         p.dilated = 1; p.chunk_major = 0;
     } else if (LEAN) {               // LEAN = 2 keeps the GELU epilogues (fc1: GELU + saved pre-activation; fc2 data gradient: x gelu'(z))
@@ -1314,7 +1314,7 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     }
     const dim3 block(256);
     static const int plain_on = getenv("PK_IGEMM_PLAIN") ? atoi(getenv("PK_IGEMM_PLAIN")) : 1;
-    const bool plain = plain_on && !a.dilated && !a.chunk_major;
+    const bool plain = plain_on && !a.dilated;
     const unsigned gm = (unsigned)((a.M + 127) / 128);
     // Deep contractions with wide outputs (the 3x3 convs of the head: K = 2304, N = 128/256): 256 x 128 workgroup tile, 128 x 64
     // per wave -- a third less LDS traffic per MFMA than the 64 x 64 wave tile, which is what bounds those kernels.

@@ -2060,7 +2060,10 @@ __device__ __forceinline__ s16x4 scale_bf16x4(const s16x4& v, const float* sc) {
     const uint32_t hi = pack_bf16x2(__uint_as_float((uint32_t)(uint16_t)v[2] << 16) * sc[2], __uint_as_float((uint32_t)(uint16_t)v[3] << 16) * sc[3]);
     return (s16x4){(short)(lo & 0xffff), (short)(lo >> 16), (short)(hi & 0xffff), (short)(hi >> 16)};
 }
-template <int TN, int TC>
+// MODE: which of the three run-time variations this instantiation serves (they were uniform run-time flags tested for every DMA piece of
+// every 32-row step; a step of the 128 x 128 tile was 445 instructions around 20 MFMAs): 0 = any (generic), 1 = A rows gathered through the
+// window partition only (qkv weight gradient), 2 = G rows gathered + scaled per sample (proj), 3 = G rows scaled only (fc2 of the unfused MLP).
+template <int TN, int TC, int MODE = 0>
 __global__ void __launch_bounds__(256, 2) k_wgrad4w(WgradArgs p) {
     constexpr int ST = (TN + TC >= 256) ? 3 : 4;                  // ring <= 48 KB + <= 8 KB of row scales: two workgroups per CU
     constexpr int PG = TN / 64, PX = TC / 64, PER = 2 * PG + PX;  // DMA instructions per wave and step: data pieces + one scale piece per G piece
@@ -2079,7 +2082,8 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4w(WgradArgs p) {
     const int m_begin = zslice * p.m_per_slice;
     const int m_end = min(p.M, m_begin + p.m_per_slice);
     const int nsteps = (max(m_end - m_begin, 0) + 31) / 32;
-    const bool gwin = p.g_rowmap != nullptr, xwin = p.a_rowmap != nullptr, scaled = p.g_scale != nullptr;     // workgroup-uniform
+    const bool gwin = MODE == 0 ? p.g_rowmap != nullptr : MODE == 2, xwin = MODE == 0 ? p.a_rowmap != nullptr : MODE == 1,
+               scaled = MODE == 0 ? p.g_scale != nullptr : MODE >= 2;     // workgroup-uniform; compile-time in the specialised instantiations
     const int nw = (p.Ws + 6) / 7, nh = (p.Hs + 6) / 7;
     const auto rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.x), 0, 0x7ffffff0, 0x00020000);
     const auto rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(p.g), 0, 0x7ffffff0, 0x00020000);
@@ -2611,10 +2615,21 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
         a.m_per_slice = ((rows + S - 1) / S + 31) / 32 * 32;
         const dim3 grid(8 * ((S + 7) / 8) * a.ntiles3);
         if (kind4 == 4) {
-            if (t4n == 64 && t4c == 64) hipLaunchKernelGGL((k_wgrad4w<64, 64>), grid, dim3(256), 0, st, a);
-            else if (t4n == 64) hipLaunchKernelGGL((k_wgrad4w<64, 128>), grid, dim3(256), 0, st, a);
-            else if (t4c == 64) hipLaunchKernelGGL((k_wgrad4w<128, 64>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((k_wgrad4w<128, 128>), grid, dim3(256), 0, st, a);
+            static const int w4_modes = getenv("PK_WGRAD4W_MODES") ? atoi(getenv("PK_WGRAD4W_MODES")) : 1;
+            const bool gw_ = a.g_rowmap != nullptr, xw_ = a.a_rowmap != nullptr, sc_ = a.g_scale != nullptr;
+            const int mode = !w4_modes ? 0 : (xw_ && !gw_ && !sc_) ? 1 : (gw_ && sc_ && !xw_) ? 2 : (sc_ && !gw_ && !xw_) ? 3 : 0;
+#define W4W_GO(TN_, TC_)                                                                                     \
+    do {                                                                                                     \
+        if (mode == 1) hipLaunchKernelGGL((k_wgrad4w<TN_, TC_, 1>), grid, dim3(256), 0, st, a);              \
+        else if (mode == 2) hipLaunchKernelGGL((k_wgrad4w<TN_, TC_, 2>), grid, dim3(256), 0, st, a);         \
+        else if (mode == 3) hipLaunchKernelGGL((k_wgrad4w<TN_, TC_, 3>), grid, dim3(256), 0, st, a);         \
+        else hipLaunchKernelGGL((k_wgrad4w<TN_, TC_, 0>), grid, dim3(256), 0, st, a);                        \
+    } while (0)
+            if (t4n == 64 && t4c == 64) W4W_GO(64, 64);
+            else if (t4n == 64) W4W_GO(64, 128);
+            else if (t4c == 64) W4W_GO(128, 64);
+            else W4W_GO(128, 128);
+#undef W4W_GO
         } else if (kind4 == 2) hipLaunchKernelGGL(k_wgrad4_3x3, grid, dim3(256), 0, st, a);
         else if (kind4 == 3 && t4n == 64) hipLaunchKernelGGL((k_wgrad4<64, 128, true>), grid, dim3(256), 0, st, a);
         else if (kind4 == 3) hipLaunchKernelGGL((k_wgrad4<128, 128, true>), grid, dim3(256), 0, st, a);

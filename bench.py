@@ -196,7 +196,7 @@ def roofline_table(model, B, trainer=None):
         u1, dq1 = torch.randn(B * 32 * 24, 64, device=dev).to(BF), torch.randn(Mw1, 192, device=dev).to(BF)
         sec = time_kernel(wgrad_slabs(u1, dq1, Mw1, 192, 64, 1, (B, 32, 24), a_map=amap1))
         E("k_wgrad4w<128,64>", f"qkv weight gradient, branch 1: {Mw1} window tokens x 192 x 64, gathered rows (slabs)", "hbm", sec,
-          flops=2.0 * Mw1 * 192 * 64, bytes_=2.0 * (Mw1 * 192 + B * 32 * 24 * 64), trace="k_wgrad4w<128, 64>(WgradArgs)")
+          flops=2.0 * Mw1 * 192 * 64, bytes_=2.0 * (Mw1 * 192 + B * 32 * 24 * 64), trace="k_wgrad4w<128, 64, 1>(WgradArgs)")      # MODE 1: A rows gathered through the window partition
         # 4. k_conv3h<64,64> (halo kernel): 3x3 conv 64->64 @64x48 (layer1), forward with BN statistics; HBM-bound by arithmetic
         x64 = torch.randn(B, H, W, 64, device=dev).to(BF)
         w64 = torch.randn(64, 9, 64, device=dev).to(BF)

@@ -791,7 +791,6 @@ struct AttnArgs {
     float* part;              // backward slabs
     int n_windows, windows_per_sample;
     float eps, softmax_scale;
-    int dbg;                  // experiment knobs (env PK_ATTN_DBG; timing only, wrong results): 1 no LDS adds, 2 no phase 2, 4 no pass 2, 8 no pass 1
 };
 #define AT_N 49
 __device__ __forceinline__ int rel_a7(int t) { return 13 * (t / 7) + t % 7; }   // rel_index(i, j) = rel_a7(i) - rel_a7(j) + 84
@@ -1416,7 +1415,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                 LDS_FENCE();                // sLse / sDelta of this wave are visible to its own reads below
                 // ---- pass 1: transposed scores, lane = query i:  dS^T, bias gradient, dQ^T = scale * K^T dS^T
 #pragma unroll
-                for (int ci = 0; ci < ((p.dbg & 8) ? 0 : 4); ++ci) {
+                for (int ci = 0; ci < 4; ++ci) {
                     const int i = 16 * ci + i16;
                     const bool iok = i < AT_N;
                     const int ai = rel_a7(iok ? i : 0) + 84;
@@ -1440,7 +1439,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                                 // d(bias)[i][j] of this window -> wave-private tile, folded onto the 169 table entries after the pass.
                                 // (LDS float atomics straight into the table were measured: ~200 cycles per ds_add_f32 wave-instruction,
                                 // 95 us of a 159 us kernel; 64 accumulator registers per head instead cost a wave of occupancy.)
-                                if (iok && ajr[r] >= 0 && !(p.dbg & 1)) sFold[wave][i * AT_N + 16 * cj + 4 * g + r] = ds[u][r];
+                                if (iok && ajr[r] >= 0) sFold[wave][i * AT_N + 16 * cj + 4 * g + r] = ds[u][r];
                             }
                         }
                         const bf16x8 df = pack2(ds[0], ds[1]);
@@ -1451,7 +1450,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                     for (int ce = 0; ce < 2; ++ce)      // rows 4g + r of tile ce  <->  head channel 8g + 4ce + r
                         if (iok) *reinterpret_cast<u32x2*>(dq_base + (size_t)i * 3 * C + 32 * h + 8 * g + 4 * ce) = pack4(dq[ce] * scale);
                 }
-                if (!(p.dbg & 1)) {        // fold: table entry e = (dy + 6) * 13 + dx + 6 sums dS[i][j] over the pairs with i - j = (dy, dx)
+                {        // fold: table entry e = (dy + 6) * 13 + dx + 6 sums dS[i][j] over the pairs with i - j = (dy, dx)
                     LDS_FENCE();
                     for (int e = lane; e < 169; e += 64) {
                         const int dy_ = e / 13 - 6, dx_ = e % 13 - 6;
@@ -1490,7 +1489,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                 }
                 // ---- pass 2: plain scores, lane = key j:  dV^T = dO^T P,  dK^T = scale * Q^T dS
 #pragma unroll
-                for (int cj = 0; cj < ((p.dbg & 4) ? 0 : 4); ++cj) {
+                for (int cj = 0; cj < 4; ++cj) {
                     const int j = 16 * cj + i16;
                     const bool jok = j < AT_N;
                     const int ajn = 84 - rel_a7(jok ? j : 0);
@@ -1535,7 +1534,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
         // GEMM will read), LayerNorm backward + residual gradient in accumulator layout, one token tile at a time
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's dqkv stores have completed before it reads them back
 #pragma unroll
-        for (int t = 0; t < ((p.dbg & 2) ? 0 : 4); ++t) {
+        for (int t = 0; t < 4; ++t) {
             const int n = 16 * t + i16;
             const int rw = row[t];
             const float mu = mean[t], rsd = rstd[t];
@@ -1636,8 +1635,6 @@ extern "C" int pk_attn_block_bwd(const void* dy, const void* x, const int32_t* r
     a.wproj_t = (const uint16_t*)wproj_t; a.o_save = (uint16_t*)const_cast<void*>(o_saved); a.lse = const_cast<float*>(lse);
     a.dqkv = (uint16_t*)dqkv; a.u_save = (uint16_t*)u_out; a.n_windows = n_windows;
     a.windows_per_sample = windows_per_sample > 0 ? windows_per_sample : 1; a.eps = eps; a.softmax_scale = 1.f / sqrtf(32.f);
-    static const int dbg = getenv("PK_ATTN_DBG") ? atoi(getenv("PK_ATTN_DBG")) : 0;
-    a.dbg = dbg;
     const dim3 grid(attn_blocks(n_windows)), block(256);
     if (C == 32) hipLaunchKernelGGL(k_attn_bwd<32>, grid, block, 0, (hipStream_t)stream, a, ln_partial, rpb_partial);
     else hipLaunchKernelGGL(k_attn_bwd<64>, grid, block, 0, (hipStream_t)stream, a, ln_partial, rpb_partial);

@@ -219,7 +219,7 @@ def roofline_table(model, B, trainer=None):
         w32 = torch.randn(32, 9, 256, device=dev).to(BF)
         sec = time_kernel(lambda: nnops._conv_raw(x, w32, 32, 3, 1, True))
         E("k_igemm2<128,32,4,1,64>", "conv3x3 256->32 @64x48 fwd + BN-stat epilogue", "mfma", sec, flops=2.0 * M * 32 * 9 * 256,
-          bytes_=2.0 * (M * 256 + M * 32), trace="k_igemm2<128, 32, 4, 1, 64, 0>(IgemmArgs)")
+          bytes_=2.0 * (M * 256 + M * 32), trace="k_igemm2<128, 32, 4, 1, 64, 3>(IgemmArgs)")
         # 5./6. the fused block halves of branch 0 (C = 32): bytes = x in + y out (forward), x + dy in, dx out (backward)
         blk = model.backbone.stage2[0].branches[0][0]
         xb = torch.randn(B, H, W, 32, device=dev).to(BF)

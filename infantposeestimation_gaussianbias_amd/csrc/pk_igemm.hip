@@ -335,8 +335,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     const int nk = (grouped ? __builtin_popcount(tapmask) : p.T) * kchunks;
     auto next_tap = [&](int t) {          // the next tap after t that this tile walks
         ++t;
-        if (grouped)
-            while (t < 9 && !(tapmask >> t & 1)) ++t;
+        if (grouped) {                    // first set bit of the tap mask at or above t (a `while` here was unrolled x8 into ~120 scalar
+            const unsigned m = tapmask >> t;                                  // instructions in the K loop of every stride-2 data gradient)
+            t = m ? t + __builtin_ctz(m) : 9;
+        }
         return t;
     };
     const int t_first = grouped ? next_tap(-1) : 0;

@@ -111,6 +111,25 @@ int pk_fusion_loss_bwd(const float* heatmaps, const float* offsets, const float*
                        float* d_heatmaps, float* d_offsets, float* d_variances,
                        int B, int K, int H, int W, float sigma_t, const float* lambdas7, void* stream);
 
+/* The same terms with COORDINATES HANDED IN by the caller: the public methods GaussianDistributionConstraint.compute_heatmap_variance /
+ * variance_alignment_loss / spatial_overlap_loss / distribution_shape_loss / forward (models/fusion_head.py:405-575) and
+ * FusionPoseLoss.heatmap_loss / offset_loss / peak_localization_loss (:637-743) take any (B,K,2) coordinates, not only the map's own
+ * soft-argmax.  coords == NULL is pk_fusion_loss_fwd.  sigma (B,K) or NULL receives compute_heatmap_variance's result.  Backward:
+ * d_coords (B,K,2) receives the coordinate gradient (NULL: the coordinates were the soft-argmax, their gradient flows into d_heatmaps);
+ * grad_sigma (B,K) or NULL is an upstream gradient on `sigma`.  A term is selected by its lambda (0 elsewhere).                         */
+int pk_fusion_terms_fwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
+                        const float* weight, const float* gt_keypoints, const float* coords, float* ws, float* losses, float* sigma,
+                        int B, int K, int H, int W, float in_w, float in_h, float sigma_t,
+                        const float* lambdas7, int use_target_weight, void* stream);
+int pk_fusion_terms_bwd(const float* heatmaps, const float* target, const float* ws, const float* grad_total,
+                        const float* grad_sigma, float* d_heatmaps, float* d_offsets, float* d_variances, float* d_coords,
+                        int B, int K, int H, int W, float sigma_t, const float* lambdas7, void* stream);
+/* LocalGaussianRefinement.forward (models/fusion_head.py:74-128) about given coordinates; backward of SoftArgmax2D.forward (:24-71)        */
+int pk_local_gaussian_refine(const float* heatmaps, const float* coords_in, float* coords_out, int BK, int H, int W,
+                             int local_radius, void* stream);
+int pk_softargmax_bwd(const float* heatmaps, const float* coords, const float* scores, const float* grad_coords,
+                      const float* grad_scores, float* d_heatmaps, int BK, int H, int W, void* stream);
+
 /* ---- L3/L4: KeypointMSELoss (models/pose_estimator.py:102-143) and models/losses.py per-pixel losses ------
  * kind 0: mean(((p-t)*w)^2)  [KeypointMSELoss]; 1: mean(w*(p-t)^2) [FusedPoseLoss mse];
  * 2: mean(w*smoothl1(p-t)) [FusedPoseLoss smoothl1]; 3: JointsMSELoss (0.5*mean((p-t)^2 w^2)).
@@ -171,6 +190,13 @@ int pk_conv_stats_rows(int B, int Hs, int Ws, int Cin, int Cout, int ksize, int 
 int pk_linear_bf16(const void* x, const void* w, void* out, const float* bias, const void* residual, const float* res_scale,
                    const int32_t* a_rowmap, const int32_t* o_rowmap, void* preact_out, const void* gelu_grad_of,
                    int M, int N, int K, int rows_per_sample, int act, int out_fp32, void* stream);
+
+/* A2 as stand-alone functions: window_partition / window_reverse (models/hrformer.py:67-114) move whole rows through the window row map
+ * (window-order token -> pixel row, -1 = zero token appended at the bottom / right).  scatter 0: dst[r] = src[rowmap[r]] (or zeros) =
+ * partition; scatter 1: dst[rowmap[r]] = src[r] where rowmap[r] >= 0 = reverse + crop.  Any element type, rows of whole dwords.
+ * drop_path (hrformer.py:15-24): out = (x / keep_prob) * mask[sample], fp32.                                                          */
+int pk_rows_by_map(const void* src, void* dst, const int32_t* rowmap, int64_t n_rows, int row_bytes, int scatter, void* stream);
+int pk_drop_path_f32(const float* x, const float* mask, float* out, int64_t batch, int64_t per_sample, float keep_prob, void* stream);
 
 /* weight gradient of either form: dw = sum_m grad_out[m]^T (x) A(m); workspace = pk_wgrad_slices(...)*N*(k*k*Cin + 1) floats.
  * out_layout 0: [N][k*k][Cin]; 1: OIHW (the reference's nn.Conv2d.weight layout).  Ho == 0 selects the linear form.

@@ -20,7 +20,10 @@ __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf
 __global__ void __launch_bounds__(256) k_floss_map(const float* __restrict__ hm, const float* __restrict__ off,
                                                    const float* __restrict__ var, const float* __restrict__ tgt,
                                                    const float* __restrict__ wt, const float* __restrict__ gt,
-                                                   float* __restrict__ stats, int H, int W, float in_w, float in_h) {
+                                                   float* __restrict__ stats, int H, int W, float in_w, float in_h,
+                                                   const float* __restrict__ ext_c) {
+    // ext_c (B*K,2) or NULL: coordinates handed in by the caller (the public methods of GaussianDistributionConstraint / FusionPoseLoss,
+    // fusion_head.py:405-575,659-743, take ANY coordinates); NULL = the soft-argmax of the map itself (FusionPoseLoss.forward, :773)
     __shared__ float red[16];
     const int map = blockIdx.x, n = H * W;
     const float* h = hm + (size_t)map * n;
@@ -49,7 +52,7 @@ __global__ void __launch_bounds__(256) k_floss_map(const float* __restrict__ hm,
     R = block_sum(R, red);
     ss = block_sum(ss, red);
     sv = block_sum(sv, red);
-    const float cx = sx / z, cy = sy / z, rinv = 1.f / (R + EPS8), zinv = 1.f / z;
+    const float cx = ext_c ? ext_c[2 * map] : sx / z, cy = ext_c ? ext_c[2 * map + 1] : sy / z, rinv = 1.f / (R + EPS8), zinv = 1.f / z;
     float ent = 0.f, ub = 0.f, sp = 0.f, qx = 0.f, qy = 0.f;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const float v = h[i], p = __expf(v - mx) * zinv;
@@ -76,16 +79,19 @@ __global__ void __launch_bounds__(256) k_floss_map(const float* __restrict__ hm,
     s[ST_GX] = gt[2 * map] * ((float)W / in_w);
     s[ST_GY] = gt[2 * map + 1] * ((float)H / in_h);
     s[ST_W] = wt[map];
-    // offsets sampled at c (border clamp; c is a convex combination of pixel centres so it is always inside)
+    // offsets sampled at c (border clamp; the soft-argmax c is a convex combination of pixel centres, i.e. always inside; external
+    // coordinates on or beyond the border sample the clamped position and get no gradient along that axis, as grid_sample's
+    // padding_mode='border' does)
     const float x = fminf(fmaxf(cx, 0.f), (float)(W - 1)), y = fminf(fmaxf(cy, 0.f), (float)(H - 1));
+    const float inx = (cx > 0.f && cx < (float)(W - 1)) ? 1.f : 0.f, iny = (cy > 0.f && cy < (float)(H - 1)) ? 1.f : 0.f;
     const int x0 = (int)floorf(x), y0 = (int)floorf(y), x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
     const float fx = x - (float)x0, fy = y - (float)y0;
     for (int ch = 0; ch < 2; ++ch) {
         const float* o = off + ((size_t)map * 2 + ch) * n;
         const float v00 = o[y0 * W + x0], v01 = o[y0 * W + x1], v10 = o[y1 * W + x0], v11 = o[y1 * W + x1];
         s[ST_OX + ch] = v00 * (1.f - fx) * (1.f - fy) + v01 * fx * (1.f - fy) + v10 * (1.f - fx) * fy + v11 * fx * fy;
-        s[ST_DOXX + 2 * ch] = (1.f - fy) * (v01 - v00) + fy * (v11 - v10);      // d o_ch / d cx
-        s[ST_DOXX + 2 * ch + 1] = (1.f - fx) * (v10 - v00) + fx * (v11 - v01);  // d o_ch / d cy
+        s[ST_DOXX + 2 * ch] = inx * ((1.f - fy) * (v01 - v00) + fy * (v11 - v10));      // d o_ch / d cx
+        s[ST_DOXX + 2 * ch + 1] = iny * ((1.f - fx) * (v10 - v00) + fx * (v11 - v01));  // d o_ch / d cy
     }
 }
 
@@ -167,29 +173,47 @@ __global__ void __launch_bounds__(256) k_floss_final(float* __restrict__ stats, 
     losses[6] = tot;
 }
 
-extern "C" int pk_fusion_loss_fwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
-                                  const float* weight, const float* gt_keypoints, float* ws, float* losses, int B, int K, int H,
-                                  int W, float in_w, float in_h, float sigma_t, const float* lambdas6, int use_target_weight, void* stream) {
+// sigma (B,K) of compute_heatmap_variance (fusion_head.py:405-448) out of the per-map statistics
+__global__ void k_floss_sigma(const float* __restrict__ stats, float* __restrict__ sigma, int BK) {
+    const int m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m < BK) sigma[m] = stats[(size_t)m * PK_LOSS_STAT + ST_SIG];
+}
+
+extern "C" int pk_fusion_terms_fwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
+                                   const float* weight, const float* gt_keypoints, const float* coords, float* ws, float* losses,
+                                   float* sigma, int B, int K, int H, int W, float in_w, float in_h, float sigma_t,
+                                   const float* lambdas6, int use_target_weight, void* stream) {
     PK_REQUIRE(heatmaps && offsets && variances && target && weight && gt_keypoints && ws && losses && lambdas6,
-               "pk_fusion_loss_fwd: null pointer");
-    PK_REQUIRE(B > 0 && K > 0 && H > 1 && W > 1 && in_w > 0 && in_h > 0 && sigma_t > 0, "pk_fusion_loss_fwd: bad shape B=%d K=%d H=%d W=%d",
+               "pk_fusion_terms_fwd: null pointer");
+    PK_REQUIRE(B > 0 && K > 0 && H > 1 && W > 1 && in_w > 0 && in_h > 0 && sigma_t > 0, "pk_fusion_terms_fwd: bad shape B=%d K=%d H=%d W=%d",
                B, K, H, W);
     float* stats = ws;
     float* pairs = ws + (size_t)B * K * PK_LOSS_STAT;
     float* glob = pairs + (size_t)B * 16 * 4;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(k_floss_map, dim3(B * K), dim3(256), 0, st, heatmaps, offsets, variances, target, weight, gt_keypoints, stats,
-                       H, W, in_w, in_h);
+                       H, W, in_w, in_h, coords);
     hipLaunchKernelGGL(k_floss_pair, dim3(B * 16), dim3(256), 0, st, heatmaps, pairs, K, H * W);
     hipLaunchKernelGGL(k_floss_final, dim3(1), dim3(256), 0, st, stats, pairs, glob, losses, B, K, sigma_t, lambdas6, use_target_weight ? 1 : 0);
-    return pk_launch_status("pk_fusion_loss_fwd");
+    if (sigma) hipLaunchKernelGGL(k_floss_sigma, dim3((B * K + 255) / 256), dim3(256), 0, st, stats, sigma, B * K);
+    return pk_launch_status("pk_fusion_terms_fwd");
+}
+
+extern "C" int pk_fusion_loss_fwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
+                                  const float* weight, const float* gt_keypoints, float* ws, float* losses, int B, int K, int H,
+                                  int W, float in_w, float in_h, float sigma_t, const float* lambdas6, int use_target_weight, void* stream) {
+    return pk_fusion_terms_fwd(heatmaps, offsets, variances, target, weight, gt_keypoints, nullptr, ws, losses, nullptr, B, K, H, W, in_w, in_h,
+                               sigma_t, lambdas6, use_target_weight, stream);
 }
 
 // ------------------------------------------------------------------------------------------------ backward
 __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm, const float* __restrict__ tgt,
                                                    const float* __restrict__ ws, const float* __restrict__ gtot,
                                                    float* __restrict__ dhm, float* __restrict__ doff, float* __restrict__ dvar,
-                                                   int B, int K, int H, int W, float sigma_t, const float* __restrict__ lam) {
+                                                   int B, int K, int H, int W, float sigma_t, const float* __restrict__ lam,
+                                                   float* __restrict__ dcoords, const float* __restrict__ gsig) {
+    // dcoords != NULL: the coordinates were handed in (k_floss_map's ext_c): their gradient goes to dcoords instead of through the
+    // soft-argmax into the heatmap.  gsig (B*K) or NULL: upstream gradient on the per-map sigma (compute_heatmap_variance).
     const int map = blockIdx.x, b = map / K, k = map - b * K, n = H * W;
     const float* s = ws + (size_t)map * PK_LOSS_STAT;
     const float* pairs = ws + (size_t)B * K * PK_LOSS_STAT;
@@ -202,11 +226,18 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
     const float ex = s[ST_OX] - (s[ST_GX] - cx), ey = s[ST_OY] - (s[ST_GY] - cy);
     const float sgx = fabsf(ex) < 1.f ? ex : (ex > 0.f ? 1.f : -1.f), sgy = fabsf(ey) < 1.f ? ey : (ey > 0.f ? 1.f : -1.f);
     const float koff = lam[1] * w3S * 0.5f;
-    const float kvar = lam[3] * wS * 2.f * (s[ST_SIG] - sigma_t) / (2.f * s[ST_SIG]);   // d total / d spread
+    const float kvar = (lam[3] * wS * 2.f * (s[ST_SIG] - sigma_t) + (gsig ? gsig[map] : 0.f)) / (2.f * s[ST_SIG]);   // d total / d spread
     float gcx = lam[2] * w3S * 2.f * (cx - s[ST_GX]) + koff * (sgx * (s[ST_DOXX] + 1.f) + sgy * s[ST_DOYX]) +
                 kvar * (-2.f) * (s[ST_QX] - cx * s[ST_QSUM]);
     float gcy = lam[2] * w3S * 2.f * (cy - s[ST_GY]) + koff * (sgx * s[ST_DOXY] + sgy * (s[ST_DOYY] + 1.f)) +
                 kvar * (-2.f) * (s[ST_QY] - cy * s[ST_QSUM]);
+    if (dcoords) {
+        if (threadIdx.x == 0) {
+            dcoords[2 * map] = gcx;
+            dcoords[2 * map + 1] = gcy;
+        }
+        gcx = gcy = 0.f;
+    }
     const float khm = lam[0] * w3S * 2.f / (float)n;
     const float ksh = lam[5] * wS * 2.f * (s[ST_ENT] - tent);
     const float ubar = s[ST_UBAR], spread = s[ST_SPREAD], rinv = 1.f / (s[ST_R] + EPS8);
@@ -265,16 +296,23 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
     }
 }
 
+extern "C" int pk_fusion_terms_bwd(const float* heatmaps, const float* target, const float* ws, const float* grad_total,
+                                   const float* grad_sigma, float* d_heatmaps, float* d_offsets, float* d_variances, float* d_coords,
+                                   int B, int K, int H, int W, float sigma_t, const float* lambdas6, void* stream) {
+    PK_REQUIRE(heatmaps && target && ws && d_heatmaps && d_offsets && d_variances && lambdas6, "pk_fusion_terms_bwd: null pointer");
+    PK_REQUIRE(B > 0 && K > 0 && H > 1 && W > 1, "pk_fusion_terms_bwd: bad shape");
+    hipLaunchKernelGGL(k_floss_bwd, dim3(B * K), dim3(256), 0, (hipStream_t)stream, heatmaps, target, ws, grad_total, d_heatmaps,
+                       d_offsets, d_variances, B, K, H, W, sigma_t, lambdas6, d_coords, grad_sigma);
+    return pk_launch_status("pk_fusion_terms_bwd");
+}
+
 extern "C" int pk_fusion_loss_bwd(const float* heatmaps, const float* offsets, const float* variances, const float* target,
                                   const float* weight, const float* ws, const float* grad_total, float* d_heatmaps,
                                   float* d_offsets, float* d_variances, int B, int K, int H, int W, float sigma_t,
                                   const float* lambdas6, void* stream) {
     (void)offsets; (void)variances; (void)weight;
-    PK_REQUIRE(heatmaps && target && ws && d_heatmaps && d_offsets && d_variances && lambdas6, "pk_fusion_loss_bwd: null pointer");
-    PK_REQUIRE(B > 0 && K > 0 && H > 1 && W > 1, "pk_fusion_loss_bwd: bad shape");
-    hipLaunchKernelGGL(k_floss_bwd, dim3(B * K), dim3(256), 0, (hipStream_t)stream, heatmaps, target, ws, grad_total, d_heatmaps,
-                       d_offsets, d_variances, B, K, H, W, sigma_t, lambdas6);
-    return pk_launch_status("pk_fusion_loss_bwd");
+    return pk_fusion_terms_bwd(heatmaps, target, ws, grad_total, nullptr, d_heatmaps, d_offsets, d_variances, nullptr, B, K, H, W, sigma_t,
+                               lambdas6, stream);
 }
 
 // ================================================================================================ L3 / L4 pixel losses

@@ -289,6 +289,114 @@ extern "C" int pk_softargmax_refine_decode(const float* heatmaps, const float* o
     return pk_launch_status("pk_softargmax_refine_decode");
 }
 
+// LocalGaussianRefinement.forward (fusion_head.py:74-128) about coordinates handed in by the caller: softmax-weighted centroid of the
+// clipped (2r+1)^2 patch around clamp(round_half_even(c)).  One lane per map (25 pixels).
+__global__ void k_local_refine(const float* __restrict__ hm, const float* __restrict__ cin, float* __restrict__ cout, int BK, int H,
+                               int W, int radius) {
+    const int map = blockIdx.x * blockDim.x + threadIdx.x;
+    if (map >= BK) return;
+    const float* m = hm + (size_t)map * H * W;
+    const int px = (int)fminf(fmaxf(rintf(cin[2 * map]), 0.f), (float)(W - 1)), py = (int)fminf(fmaxf(rintf(cin[2 * map + 1]), 0.f), (float)(H - 1));
+    const int x0 = max(0, px - radius), x1 = min(W, px + radius + 1), y0 = max(0, py - radius), y1 = min(H, py + radius + 1);
+    float lm = -INFINITY;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) lm = fmaxf(lm, m[y * W + x]);
+    float lz = 0.f, lx = 0.f, ly = 0.f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) {
+            const float e = __expf(m[y * W + x] - lm);
+            lz += e;
+            lx += e * (float)x;
+            ly += e * (float)y;
+        }
+    cout[2 * map] = lx / lz;
+    cout[2 * map + 1] = ly / lz;
+}
+extern "C" int pk_local_gaussian_refine(const float* heatmaps, const float* coords_in, float* coords_out, int BK, int H, int W,
+                                        int local_radius, void* stream) {
+    PK_REQUIRE(heatmaps && coords_in && coords_out && BK > 0 && H > 0 && W > 0 && local_radius >= 0, "pk_local_gaussian_refine: bad argument");
+    hipLaunchKernelGGL(k_local_refine, dim3((BK + 255) / 256), dim3(256), 0, (hipStream_t)stream, heatmaps, coords_in, coords_out, BK, H, W,
+                       local_radius);
+    return pk_launch_status("pk_local_gaussian_refine");
+}
+
+// Backward of SoftArgmax2D.forward (fusion_head.py:24-71): coords = sum softmax(h) (x, y), scores = max h.
+//   d h_i = p_i ((x_i - c_x) g_cx + (y_i - c_y) g_cy) + g_score [i == first arg max]
+__global__ void __launch_bounds__(256) k_softargmax_bwd(const float* __restrict__ hm, const float* __restrict__ coords,
+                                                        const float* __restrict__ scores, const float* __restrict__ gco,
+                                                        const float* __restrict__ gsc, float* __restrict__ dhm, int H, int W) {
+    __shared__ float red[16];
+    __shared__ int first;
+    const int map = blockIdx.x, n = H * W;
+    const float* m = hm + (size_t)map * n;
+    const float mx = scores[map], cx = coords[2 * map], cy = coords[2 * map + 1];
+    float z = 0.f;
+    int arg = n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const float v = m[i];
+        z += __expf(v - mx);
+        if (v == mx && i < arg) arg = i;
+    }
+    z = block_sum(z, red);
+    if (threadIdx.x == 0) first = n;
+    __syncthreads();
+    atomicMin(&first, arg);
+    __syncthreads();
+    const float zinv = 1.f / z, gx = gco ? gco[2 * map] : 0.f, gy = gco ? gco[2 * map + 1] : 0.f, gs = gsc ? gsc[map] : 0.f;
+    float* d = dhm + (size_t)map * n;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        const int y = i / W;
+        const float p = __expf(m[i] - mx) * zinv;
+        d[i] = p * (((float)(i - y * W) - cx) * gx + ((float)y - cy) * gy) + (i == first ? gs : 0.f);
+    }
+}
+extern "C" int pk_softargmax_bwd(const float* heatmaps, const float* coords, const float* scores, const float* grad_coords,
+                                 const float* grad_scores, float* d_heatmaps, int BK, int H, int W, void* stream) {
+    PK_REQUIRE(heatmaps && coords && scores && d_heatmaps && BK > 0 && H > 0 && W > 0, "pk_softargmax_bwd: bad argument");
+    hipLaunchKernelGGL(k_softargmax_bwd, dim3(BK), dim3(256), 0, (hipStream_t)stream, heatmaps, coords, scores, grad_coords, grad_scores,
+                       d_heatmaps, H, W);
+    return pk_launch_status("pk_softargmax_bwd");
+}
+
+// window_partition / window_reverse (hrformer.py:67-114) as row moves through the window row map (window-order token -> pixel row, -1 = one
+// of the zero tokens appended at the bottom / right): gather = partition (pad tokens read as zeros), scatter = reverse (pad tokens dropped).
+// Rows are `row_dwords` 4-byte words of any element type.
+__global__ void k_rows_by_map(const uint32_t* __restrict__ src, uint32_t* __restrict__ dst, const int* __restrict__ map, long n_rows,
+                              int row_dwords, int scatter) {
+    const long total = n_rows * row_dwords;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / row_dwords;
+        const int c = (int)(i - r * row_dwords), pr = map[r];
+        if (scatter) {
+            if (pr >= 0) dst[(long)pr * row_dwords + c] = src[i];
+        } else {
+            dst[i] = pr >= 0 ? src[(long)pr * row_dwords + c] : 0u;
+        }
+    }
+}
+extern "C" int pk_rows_by_map(const void* src, void* dst, const int* rowmap, int64_t n_rows, int row_bytes, int scatter, void* stream) {
+    PK_REQUIRE(src && dst && rowmap && n_rows > 0 && row_bytes > 0 && row_bytes % 4 == 0, "pk_rows_by_map: bad argument (rows of whole dwords)");
+    const long total = n_rows * (row_bytes / 4);
+    const int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_rows_by_map, dim3(nb), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)src, (uint32_t*)dst, rowmap, (long)n_rows,
+                       row_bytes / 4, scatter);
+    return pk_launch_status("pk_rows_by_map");
+}
+
+// drop_path (hrformer.py:15-24): out = (x / keep) * mask[sample], mask in {0, 1}; fp32 elements, `per_sample` of them per sample.
+__global__ void k_drop_path(const float* __restrict__ x, const float* __restrict__ mask, float* __restrict__ out, long total, long per_sample,
+                            float keep) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        out[i] = (x[i] / keep) * mask[i / per_sample];
+}
+extern "C" int pk_drop_path_f32(const float* x, const float* mask, float* out, int64_t batch, int64_t per_sample, float keep_prob, void* stream) {
+    PK_REQUIRE(x && mask && out && batch > 0 && per_sample > 0 && keep_prob > 0.f, "pk_drop_path_f32: bad argument");
+    const long total = batch * per_sample;
+    const int nb = (int)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+    hipLaunchKernelGGL(k_drop_path, dim3(nb), dim3(256), 0, (hipStream_t)stream, x, mask, out, total, (long)per_sample, keep_prob);
+    return pk_launch_status("pk_drop_path_f32");
+}
+
 // ================================================================================================ D3 tail
 __global__ void k_window_refine(const float* __restrict__ hm, const float* __restrict__ cin, float* __restrict__ cout, int BK,
                                 int H, int W, int window) {

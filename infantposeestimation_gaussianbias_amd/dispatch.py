@@ -53,6 +53,7 @@ def scope(model):
     try:
         with nnops.use_weights(model):
             yield ops
+            join_detached()
     finally:
         _ACTIVE.pop()
 
@@ -130,6 +131,35 @@ def join_side_streams(cur=None):
     cur = cur or torch.cuda.current_stream()
     for s in _SIDE.values():
         cur.wait_stream(s)
+
+
+_DETACHED = []
+
+
+def run_detached(fn, tensors):
+    """Run fn() without autograd on a dedicated side stream that nothing waits for until the outermost `scope` exits (`join_detached`):
+    work whose results nobody reads in this pass (the unused exchange outputs of the last module: only their BatchNorm running-statistics
+    updates survive).  `tensors`: what fn reads."""
+    with torch.no_grad():
+        if not streams_enabled() or _MARK:
+            fn()
+            return
+        cur = torch.cuda.current_stream()
+        s = _side_stream(cur.device, 7)
+        _order(cur, s)
+        with torch.cuda.stream(s):
+            for t in tensors:
+                t.record_stream(s)
+            fn()
+        _DETACHED.append(s)
+
+
+def join_detached():
+    if _DETACHED:
+        cur = torch.cuda.current_stream()
+        for s in _DETACHED:
+            _order(s, cur)
+        _DETACHED.clear()
 
 
 # (Measured and removed: issuing the weight-gradient kernels on auxiliary streams -- they are off the data-gradient dependency

@@ -177,6 +177,148 @@ def fusion_loss(hm, off, var, target, weight, gt, input_size, sigma_t, lambdas_d
                              bool(use_target_weight))
 
 
+class _FusionTerms(torch.autograd.Function):
+    """The seven loss values of pk_fusion_terms_fwd with the coordinates HANDED IN (None = the maps' own soft-argmax) plus the per-map
+    sigma of compute_heatmap_variance; gradients for heatmaps, offsets, variances and the coordinates (fusion_head.py:405-575,637-743)."""
+
+    @staticmethod
+    def forward(ctx, hm, off, var, coords, target, weight, gt, in_w, in_h, sigma_t, lambdas, use_target_weight):
+        hm, off, var = _chk(hm, name="heatmaps"), _chk(off, name="offsets"), _chk(var, name="variances")
+        target, weight, gt = _chk(target), _chk(weight), _chk(gt)
+        co = None if coords is None else _chk(coords, name="coords")
+        B, K, H, W = hm.shape
+        if off.shape != (B, K, 2, H, W) or var.shape != hm.shape or target.shape != hm.shape or weight.numel() != B * K or gt.shape != (B, K, 2) \
+                or (co is not None and co.shape != (B, K, 2)):
+            raise _lib.PoseKernelError("fusion terms: inconsistent shapes")
+        lambdas = _chk(lambdas.float(), name="lambdas")
+        ws = torch.empty(loss_ws_floats(B, K), dtype=F32, device=hm.device)
+        losses = torch.empty(7, dtype=F32, device=hm.device)
+        sigma = torch.empty(B, K, dtype=F32, device=hm.device)
+        call("pk_fusion_terms_fwd", hm, off, var, target, weight, gt, co, ws, losses, sigma, B, K, H, W, float(in_w), float(in_h), float(sigma_t),
+             lambdas, 1 if use_target_weight else 0, stream_ptr())
+        ctx.save_for_backward(hm, target, ws, lambdas)
+        ctx.meta = (float(sigma_t), co is not None, tuple(off.shape))
+        return losses, sigma
+
+    @staticmethod
+    def backward(ctx, g, gsig):
+        hm, target, ws, lambdas = ctx.saved_tensors
+        sigma_t, ext, off_shape = ctx.meta
+        B, K, H, W = hm.shape
+        eff = torch.cat([lambdas[:6] * (g[:6] + g[6]), lambdas[6:7]]).contiguous()
+        dhm, dvar = torch.empty_like(hm), torch.empty_like(hm)
+        doff = torch.empty(off_shape, dtype=F32, device=hm.device)
+        dco = torch.empty(B, K, 2, dtype=F32, device=hm.device) if ext else None
+        call("pk_fusion_terms_bwd", hm, target, ws, None, None if gsig is None else _chk(gsig.float()), dhm, doff, dvar, dco, B, K, H, W,
+             sigma_t, eff, stream_ptr())
+        return dhm, doff, dvar, dco, None, None, None, None, None, None, None, None
+
+
+def fusion_terms(lambdas7, hm=None, off=None, var=None, coords=None, target=None, weight=None, gt=None, input_size=(1.0, 1.0),
+                 sigma_t=2.0, use_target_weight=True, shape=None):
+    """Per-term access to the fused loss kernels for the reference's public loss methods: inputs a method does not take are replaced by
+    neutral device tensors (zero maps; variances == sigma_t, whose term is then exactly 0) and masked out by a zero lambda.
+    -> (losses (7,), sigma (B,K))."""
+    ref = hm if hm is not None else (off if off is not None else coords)
+    dev = ref.device
+    B, K, H, W = shape if shape is not None else hm.shape
+    z = None
+
+    def zeros():
+        nonlocal z
+        if z is None:
+            z = torch.zeros(B, K, H, W, dtype=F32, device=dev)
+        return z
+
+    hm = zeros() if hm is None else hm.float()
+    off = torch.zeros(B, K, 2, H, W, dtype=F32, device=dev) if off is None else off.float().reshape(B, K, 2, H, W)
+    var = torch.full((B, K, H, W), float(sigma_t), dtype=F32, device=dev) if var is None else var.float()
+    target = zeros() if target is None else target.float()
+    weight = torch.ones(B, K, 1, dtype=F32, device=dev) if weight is None else weight.float()
+    gt = torch.zeros(B, K, 2, dtype=F32, device=dev) if gt is None else gt.float()
+    lam = torch.as_tensor(lambdas7, dtype=F32, device=dev) if not torch.is_tensor(lambdas7) else lambdas7
+    return _FusionTerms.apply(hm, off, var, None if coords is None else coords.float(), target, weight, gt, float(input_size[0]),
+                              float(input_size[1]), float(sigma_t), lam, bool(use_target_weight))
+
+
+class _SoftArgmax(torch.autograd.Function):
+    """SoftArgmax2D.forward with gradients (fusion_head.py:24-71): coords through the softmax, scores to the first maximum."""
+
+    @staticmethod
+    def forward(ctx, hm):
+        hm = _chk(hm, name="heatmaps")
+        one = torch.full((1,), 40.0, device=hm.device)          # sigmoid(40) == 1: pure global soft-argmax
+        co, sc = softargmax_refine_decode(hm, None, one, None, radius=0)
+        ctx.save_for_backward(hm, co, sc)
+        return co, sc
+
+    @staticmethod
+    def backward(ctx, gco, gsc):
+        hm, co, sc = ctx.saved_tensors
+        B, K, H, W = hm.shape
+        dhm = torch.empty_like(hm)
+        call("pk_softargmax_bwd", hm, co, sc, None if gco is None else _chk(gco.float()), None if gsc is None else _chk(gsc.float()), dhm,
+             B * K, H, W, stream_ptr())
+        return dhm
+
+
+def softargmax(hm):
+    return _SoftArgmax.apply(hm)
+
+
+def local_gaussian_refine(heatmaps, coords, radius=2):
+    hm, c = _chk(heatmaps, name="heatmaps"), _chk(coords, name="coords")
+    B, K, H, W = hm.shape
+    out = torch.empty_like(c)
+    call("pk_local_gaussian_refine", hm, c, out, B * K, H, W, int(radius), stream_ptr())
+    return out
+
+
+class _RowsByMap(torch.autograd.Function):
+    """Rows moved through an int32 row map (window_partition = gather, window_reverse = scatter); the backward is the opposite move."""
+
+    @staticmethod
+    def forward(ctx, x2d, rowmap, n_out, scatter):
+        x2d = x2d.contiguous()
+        if not x2d.is_cuda or (x2d.shape[1] * x2d.element_size()) % 4:
+            raise _lib.PoseKernelError("rows_by_map: CUDA(HIP) tensor with rows of whole dwords expected")
+        out = (torch.zeros if scatter else torch.empty)((n_out, x2d.shape[1]), dtype=x2d.dtype, device=x2d.device)
+        call("pk_rows_by_map", x2d, out, rowmap, rowmap.numel(), x2d.shape[1] * x2d.element_size(), 1 if scatter else 0, stream_ptr())
+        ctx.save_for_backward(rowmap)
+        ctx.meta = (x2d.shape[0], scatter)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (rowmap,) = ctx.saved_tensors
+        n_in, scatter = ctx.meta
+        return _RowsByMap.apply(g, rowmap, n_in, not scatter), None, None, None
+
+
+def rows_by_map(x2d, rowmap, n_out, scatter):
+    return _RowsByMap.apply(x2d, rowmap, n_out, scatter)
+
+
+class _DropPath(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, mask, keep):
+        x = _chk(x, name="x")
+        out = torch.empty_like(x)
+        call("pk_drop_path_f32", x, mask, out, x.shape[0], x.numel() // x.shape[0], float(keep), stream_ptr())
+        ctx.save_for_backward(mask)
+        ctx.keep = keep
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return _DropPath.apply(g.float().contiguous(), mask, ctx.keep), None, None
+
+
+def drop_path(x, mask, keep):
+    return _DropPath.apply(x, mask, keep)
+
+
 class _PixelLoss(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pred, target, weight, kind):

@@ -5,6 +5,7 @@ Everything numerical runs in libposekernels: `decode` is one kernel per batch (n
 `FusionPoseLoss` is a fused forward (3 launches) + a hand-derived backward (1 launch).
 """
 import math
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -16,26 +17,48 @@ from ._blocks import conv
 
 
 class SoftArgmax2D(nn.Module):
-    """Soft-argmax coordinates + raw-max scores (fusion_head.py:24-71). beta must be 1 (the only value the reference uses)."""
+    """Soft-argmax coordinates + raw-max scores (fusion_head.py:24-71), differentiable (coordinates through the softmax, scores to the
+    first maximum: pk_softargmax_bwd)."""
 
     def __init__(self, beta: float = 1.0):
         super().__init__()
         self.beta = beta
 
     def forward(self, heatmaps: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        h = heatmaps.float()
+        if torch.is_grad_enabled() and h.requires_grad:
+            co, sc = hipops.softargmax(h)
+            if self.beta != 1.0:  # coordinates from softmax(beta * H), scores stay the raw maxima (fusion_head.py:50-69)
+                co = hipops.softargmax(h * self.beta)[0]
+            return co, sc
         one = torch.full((1,), 40.0, device=heatmaps.device)          # sigmoid(40) == 1: pure global soft-argmax
-        co, sc = hipops.softargmax_refine_decode(heatmaps.float(), None, one, None, radius=0)
-        if self.beta != 1.0:      # coordinates from softmax(beta * H), scores stay the raw maxima (fusion_head.py:50-69); decode-time only
-            co, _ = hipops.softargmax_refine_decode((heatmaps.float() * self.beta).contiguous(), None, one, None, radius=0)
+        co, sc = hipops.softargmax_refine_decode(h, None, one, None, radius=0)
+        if self.beta != 1.0:
+            co, _ = hipops.softargmax_refine_decode((h * self.beta).contiguous(), None, one, None, radius=0)
         return co, sc
 
 
+class LocalGaussianRefinement(nn.Module):
+    """Softmax-weighted centroid of the clipped (2r+1)^2 patch around round(coarse_coords) (fusion_head.py:74-128), one kernel for the
+    batch instead of the reference's B x K Python loop with .item(); like the reference's, the result carries no gradient."""
+
+    def __init__(self, local_radius: int = 2):
+        super().__init__()
+        self.local_radius = local_radius
+
+    @torch.no_grad()
+    def forward(self, heatmaps: torch.Tensor, coarse_coords: torch.Tensor) -> torch.Tensor:
+        return hipops.local_gaussian_refine(heatmaps.float(), coarse_coords.float(), self.local_radius)
+
+
 class SubPixelRefinement(nn.Module):
-    """Holds `alpha` (fusion_head.py:131-172); the blend itself happens inside the decode kernel."""
+    """alpha * global soft-argmax + (1 - alpha) * local centroid (fusion_head.py:131-172); the blend happens inside the decode kernel."""
 
     def __init__(self, beta: float = 1.0, local_radius: int = 2, fusion_alpha: float = 0.5):
         super().__init__()
         self.local_radius = local_radius
+        self.soft_argmax = SoftArgmax2D(beta=beta)
+        self.local_refine = LocalGaussianRefinement(local_radius=local_radius)
         self.alpha = nn.Parameter(torch.tensor(fusion_alpha))
 
     def forward(self, heatmaps):
@@ -85,8 +108,11 @@ class HeatmapRegressionHead(nn.Module):
 
         # the three branches are independent: on concurrent streams their small BatchNorm kernels (finalize, partial sums: a
         # handful of workgroups each) hide under another branch's convolution instead of leaving the GPU idle
-        heatmaps, offsets, variances = nnops.parallel([make(self.heatmap_branch), make(self.offset_branch), make(self.variance_branch, True)],
-                                                      [[f], [f], [f]])
+        fns = [make(self.heatmap_branch), make(self.offset_branch), make(self.variance_branch, True)]
+        if os.environ.get("POSE_HEAD_SERIAL", "0") == "1":
+            heatmaps, offsets, variances = [fn([f]) for fn in fns]
+        else:
+            heatmaps, offsets, variances = nnops.parallel(fns, [[f], [f], [f]])
         B, _, H, W = offsets.shape
         return {"heatmaps": heatmaps, "offsets": offsets.view(B, self.num_keypoints, 2, H, W),
                 "variances": variances, "fusion_weight": torch.sigmoid(self.fusion_weight)}
@@ -106,14 +132,47 @@ class HeatmapRegressionHead(nn.Module):
         return hipops.softargmax_refine_decode(hm, outputs["offsets"].float(), alpha, raw, radius)
 
 
+_TERM = {"heatmap": 0, "offset": 1, "peak": 2, "variance": 3, "overlap": 4, "shape": 5}
+
+
+def _lam(dev, thr=0.5, **terms):
+    v = [0.0] * 6 + [float(thr)]
+    for k, w in terms.items():
+        v[_TERM[k]] = float(w)
+    return torch.tensor(v, dtype=torch.float32, device=dev)
+
+
 class GaussianDistributionConstraint(nn.Module):
-    """Kept for API parity (fusion_head.py:372-575); its three terms are computed inside the fused loss kernel."""
+    """Variance-alignment, spatial-overlap and distribution-shape terms (fusion_head.py:372-575) on ANY coordinates, each a binding of
+    the fused loss kernels (pk_fusion_terms_fwd / _bwd: one term selected by its lambda); gradients flow to the heatmaps, the
+    coordinates and the predicted variances as in the reference."""
     SKELETON = [(0, 1), (0, 2), (1, 3), (2, 4), (5, 6), (5, 7), (7, 9), (6, 8), (8, 10), (5, 11), (6, 12), (11, 12),
                 (11, 13), (13, 15), (12, 14), (14, 16)]
 
     def __init__(self, target_sigma: float = 2.0, overlap_threshold: float = 0.5):
         super().__init__()
         self.target_sigma, self.overlap_threshold = target_sigma, overlap_threshold
+
+    def _terms(self, heatmaps, coords, target_weight, pred_variances, **terms):
+        return hipops.fusion_terms(_lam(heatmaps.device, self.overlap_threshold, **terms), hm=heatmaps, var=pred_variances, coords=coords,
+                                   weight=target_weight, sigma_t=self.target_sigma)
+
+    def compute_heatmap_variance(self, heatmaps: torch.Tensor, coords: torch.Tensor) -> torch.Tensor:
+        """sigma (B,K) = sqrt(second moment of relu(H)/sum about coords + 1e-8) (fusion_head.py:405-448)."""
+        return self._terms(heatmaps, coords, None, None)[1]
+
+    def variance_alignment_loss(self, heatmaps, coords, target_weight, pred_variances: Optional[torch.Tensor] = None) -> torch.Tensor:
+        return self._terms(heatmaps, coords, target_weight, pred_variances, variance=1.0)[0][3]
+
+    def spatial_overlap_loss(self, heatmaps, target_weight) -> torch.Tensor:
+        return self._terms(heatmaps, None, target_weight, None, overlap=1.0)[0][4]
+
+    def distribution_shape_loss(self, heatmaps, target_weight) -> torch.Tensor:
+        return self._terms(heatmaps, None, target_weight, None, shape=1.0)[0][5]
+
+    def forward(self, heatmaps, coords, target_weight, pred_variances: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:
+        v = self._terms(heatmaps, coords, target_weight, pred_variances, variance=1.0, overlap=1.0, shape=1.0)[0]
+        return {"variance_loss": v[3], "overlap_loss": v[4], "shape_loss": v[5]}
 
 
 class FusionPoseLoss(nn.Module):
@@ -130,6 +189,24 @@ class FusionPoseLoss(nn.Module):
         self.soft_argmax = SoftArgmax2D()
         self.register_buffer("_lambdas", torch.tensor([heatmap_weight, offset_weight, peak_weight, variance_weight, overlap_weight, shape_weight,
                                                        self.gaussian_constraint.overlap_threshold], dtype=torch.float32), persistent=False)
+
+    # the three term methods of the reference (fusion_head.py:637-743), each on its own inputs
+    def heatmap_loss(self, pred, target, weight) -> torch.Tensor:
+        return hipops.fusion_terms(_lam(pred.device, heatmap=1.0), hm=pred, target=target, weight=weight,
+                                   use_target_weight=self.use_target_weight)[0][0]
+
+    def offset_loss(self, pred_offsets, pred_coords, gt_coords, weight, input_size, heatmap_size) -> torch.Tensor:
+        """SmoothL1(offsets sampled at pred_coords, gt * (W/in_w, H/in_h) - pred_coords); heatmap_size = (H, W) (fusion_head.py:659-712)."""
+        B, K = pred_coords.shape[:2]
+        H, W = heatmap_size
+        return hipops.fusion_terms(_lam(pred_offsets.device, offset=1.0), off=pred_offsets, coords=pred_coords, gt=gt_coords, weight=weight,
+                                   input_size=input_size, use_target_weight=self.use_target_weight, shape=(B, K, H, W))[0][1]
+
+    def peak_localization_loss(self, pred_coords, gt_coords, weight, input_size, heatmap_size) -> torch.Tensor:
+        B, K = pred_coords.shape[:2]
+        H, W = heatmap_size
+        return hipops.fusion_terms(_lam(pred_coords.device, peak=1.0), coords=pred_coords, gt=gt_coords, weight=weight, input_size=input_size,
+                                   use_target_weight=self.use_target_weight, shape=(B, K, H, W))[0][2]
 
     def forward(self, outputs, target_heatmaps, target_weight, gt_keypoints, input_size=(192, 256), heatmap_size=(48, 64)):
         vals = hipops.fusion_loss(outputs["heatmaps"], outputs["offsets"], outputs["variances"], target_heatmaps.float(),

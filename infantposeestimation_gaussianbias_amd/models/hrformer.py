@@ -16,6 +16,51 @@ from .. import dispatch as nnops
 from ._blocks import Residual, conv, init_backbone_weights, make_fuse_layers, make_transition, run_transition, transition_branch
 
 
+def drop_path(x: torch.Tensor, drop_prob: float = 0., training: bool = False) -> torch.Tensor:
+    """Stochastic depth per sample (hrformer.py:15-24): (x / keep) * floor(keep + U[0,1)) with one draw per sample; identity when
+    drop_prob is 0 or not training.  The draw comes from torch's device generator, the scaling is pk_drop_path_f32."""
+    if drop_prob == 0. or not training:
+        return x
+    from .. import hipops
+    keep = 1.0 - drop_prob
+    mask = torch.floor(keep + torch.rand(x.shape[0], dtype=torch.float32, device=x.device))
+    return hipops.drop_path(x.float().contiguous(), mask, keep).to(x.dtype)
+
+
+class DropPath(nn.Module):
+    """hrformer.py:27-35.  (Inside HRFormerBlock the two draws of a block are applied in the GEMM epilogues, not through this module.)"""
+
+    def __init__(self, drop_prob: float = 0.):
+        super().__init__()
+        self.drop_prob = drop_prob
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        return drop_path(x, self.drop_prob, self.training)
+
+
+def window_partition(x: torch.Tensor, window_size: int):
+    """(B,H,W,C) -> ((B*nW, ws, ws, C) windows, (Hp, Wp)); zero tokens appended at the bottom / right (hrformer.py:67-91).  Inside the
+    network the partition is a row map consumed by the GEMMs; this stand-alone form moves the rows with pk_rows_by_map."""
+    if window_size != 7:
+        raise ValueError("window size must be 7")
+    from .. import hipops, nnops as _nn
+    B, H, W, C = x.shape
+    rowmap, nwin = _nn.window_rowmap(B, H, W, x.device)
+    wins = hipops.rows_by_map(x.reshape(B * H * W, C), rowmap, rowmap.numel(), False)
+    return wins.view(B * nwin, 7, 7, C), (-(-H // 7) * 7, -(-W // 7) * 7)
+
+
+def window_reverse(windows: torch.Tensor, window_size: int, H: int, W: int, Hp: int, Wp: int) -> torch.Tensor:
+    """(B*nW, ws, ws, C) -> (B,H,W,C), the padded rows / columns cropped (hrformer.py:94-114)."""
+    if window_size != 7:
+        raise ValueError("window size must be 7")
+    from .. import hipops, nnops as _nn
+    B = int(windows.shape[0] / (Hp * Wp / 49))
+    C = windows.shape[-1]
+    rowmap, _ = _nn.window_rowmap(B, H, W, windows.device)
+    return hipops.rows_by_map(windows.reshape(-1, C), rowmap, B * H * W, True).view(B, H, W, C)
+
+
 class WindowAttentionParams(nn.Module):
     """qkv/proj + relative-position table (169, heads) + the (49,49) index buffer (hrformer.py:147-170)."""
 
@@ -90,7 +135,7 @@ class HRFormerModule(nn.Module):
     def n_draws(self):
         return 2 * sum(len(b) for b in self.branches)
 
-    def forward(self, xs, scales=None, pre=None, defer=False, trans=None):
+    def forward(self, xs, scales=None, pre=None, defer=False, trans=None, first_only=False):
         """scales: (n_draws, B) DropPath multipliers for this module (two per block, branch-major), or None.
 
         Chaining (same stage, same branch count): with `defer=True` the module returns its branch outputs WITHOUT the exchange unit;
@@ -121,7 +166,7 @@ class HRFormerModule(nn.Module):
         ys = nnops.parallel(fns, [(list(xs) if pre is not None else [xs[min(b, n_prev - 1)]]) + extra for b in range(len(fns))])
         if len(ys) == 1 or defer:
             return ys
-        return nnops.exchange(ys, self.fuse_layers, self.training)
+        return nnops.exchange(ys, self.fuse_layers, self.training, first_only=first_only)
 
 
 class HRFormer(nn.Module):
@@ -185,7 +230,8 @@ class HRFormer(nn.Module):
             for k, m in enumerate(mods_s):
                 n = m.n_draws()
                 chain = _CHAIN and k + 1 < len(mods_s)          # the exchange unit of this module runs inside the next module's tasks
-                ys = m(ys, None if scales is None else scales[d:d + n], pre=pre, defer=chain, trans=trans if k == 0 else None)
+                ys = m(ys, None if scales is None else scales[d:d + n], pre=pre, defer=chain, trans=trans if k == 0 else None,
+                       first_only=(s == 4 and k + 1 == len(mods_s)))
                 pre = m.fuse_layers if chain else None
                 d += n
             # N > 1: once backward has passed this boundary the later stages' gradients are exchanged while the earlier stages still

@@ -20,7 +20,7 @@ class HighResolutionModule(nn.Module):
         if len(channels) > 1:
             self.fuse_layers = make_fuse_layers(channels)
 
-    def forward(self, xs, pre=None, defer=False, trans=None):
+    def forward(self, xs, pre=None, defer=False, trans=None, first_only=False):
         """`pre` / `defer` / `trans`: chained modules, see HRFormerModule.forward (the previous module's exchange output i, or branch i
         of the stage's transition, is computed inside this module's branch task i)."""
         n_prev = len(xs)
@@ -37,7 +37,7 @@ class HighResolutionModule(nn.Module):
 
         ys = nnops.parallel([make(b, blocks) for b, blocks in enumerate(self.branches)],
                             [(list(xs) if pre is not None else [xs[min(b, n_prev - 1)]]) for b in range(len(self.branches))])
-        return ys if (len(ys) == 1 or defer) else nnops.exchange(ys, self.fuse_layers, self.training)
+        return ys if (len(ys) == 1 or defer) else nnops.exchange(ys, self.fuse_layers, self.training, first_only=first_only)
 
 
 _CHAIN = os.environ.get("POSE_CHAIN_MODULES", "1") != "0"
@@ -84,7 +84,7 @@ class HRNet(nn.Module):
             mods_s, pre = list(getattr(self, f"stage{s}")), None
             for k, m in enumerate(mods_s):
                 chain = _CHAIN and k + 1 < len(mods_s)
-                ys = m(ys, pre=pre, defer=chain, trans=trans if k == 0 else None)
+                ys = m(ys, pre=pre, defer=chain, trans=trans if k == 0 else None, first_only=(s == 4 and k + 1 == len(mods_s)))
                 pre = m.fuse_layers if chain else None
             # N > 1: once backward has passed this boundary the later stages' gradients are exchanged while the earlier stages still
             # run backward (only output 0 of the last stage is consumed, hrformer.py:776 / hrnet.py:441)

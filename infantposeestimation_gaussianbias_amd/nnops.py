@@ -805,6 +805,7 @@ def rel_table(attn, heads):
     key = (str(dev), heads)
     if key not in _ZERO_TABLES:
         _ZERO_TABLES[key] = torch.zeros(169, heads, dtype=F32, device=dev)
+        _ZERO_TABLES[key]._pk_zero_table = True
     return _ZERO_TABLES[key]
 
 
@@ -979,11 +980,16 @@ class _AttnHalfFused(torch.autograd.Function):
         nwin, Mw = nw // B, nw * WS * WS
         dy = dy.contiguous()
         pg1, pb1, ptab, pwqkv, pbqkv, pwproj, pbproj = ctx.params
-        (dg, sg), (db, sb), (dtable, s_t) = _sink(pg1), _sink(pb1), _sink(ptab)
+        (dg, sg), (db, sb) = _sink(pg1), _sink(pb1)
+        # with_rpe=False (hrformer.py:145-191): the table is the shared all-zero constant, not a parameter -- its partial sums go to a
+        # scratch workspace nobody reduces, so the LayerNorm rows keep the deferred (hipGraph-capturable) path
+        no_tab = getattr(ptab, "_pk_zero_table", False)
+        dtable, s_t = (None, True) if no_tab else _sink(ptab)
         nb = _lib.lib.pk_attn_block_blocks(nw)
         small_sinks = sg and sb and s_t and deferral_enabled()
         if small_sinks:
-            lnp, rpb = _workspace(dg, "attn_ln", nb * 2 * C), _workspace(dtable, "attn_rpb", nb * 4 * heads * 169)
+            lnp = _workspace(dg, "attn_ln", nb * 2 * C)
+            rpb = _workspace(dg if no_tab else dtable, "attn_rpb_void" if no_tab else "attn_rpb", nb * 4 * heads * 169)
         else:
             lnp, rpb = _e((nb * 2 * C,), F32, dev), _e((nb * 4 * heads * 169,), F32, dev)
         dx = _e((B, H, W, C), BF16, dev)
@@ -991,7 +997,7 @@ class _AttnHalfFused(torch.autograd.Function):
         call("pk_attn_block_bwd", dy, x, amap, g1, b1, table, wqkv_f, bqkv, wqkv_t, wproj_t, s1, o, lse, dx, dqkv, u_w, lnp, rpb, nw, nwin,
              heads, C, 1e-5, stream_ptr())
         rows = [(lnp.data_ptr(), dg.data_ptr(), 2 * C, nb, C, 0, 0, 1, 1, 1, 0), (lnp.data_ptr() + 4 * C, db.data_ptr(), 2 * C, nb, C, 0, 0, 1, 1, 1, 0)]
-        for hh in range(heads):              # partial [wave][head][169] -> table[e][head]
+        for hh in range(0 if no_tab else heads):              # partial [wave][head][169] -> table[e][head]
             rows.append((rpb.data_ptr() + 4 * 169 * hh, dtable.data_ptr() + 4 * hh, 169 * heads, nb * 4, 169, 0, 0, 1, 1, heads, 0))
         if small_sinks:
             _PENDING.extend(rows)
@@ -1091,7 +1097,7 @@ def fuse_sum(xs, relu=True):
     return _FuseSum.apply(relu, *xs)
 
 
-def exchange(xs, fuse, training, n_out=None):
+def exchange(xs, fuse, training, n_out=None, first_only=False):
     """Exchange unit (hrformer.py:462-491 == hrnet.py:198-227): out_i = relu(sum_j route_{j->i}(x_j)).
 
     One parallel task per OUTPUT.  (Measured and dropped: one task per ROUTE j -> i, i.e. 12 shorter chains plus a second region for
@@ -1102,6 +1108,16 @@ def exchange(xs, fuse, training, n_out=None):
     kernels in flight, profiles/r02_trace_summary.txt.)"""
     from . import dispatch
     n = len(xs)
+    if first_only and n > 1 and os.environ.get("POSE_LAST_EXCHANGE_DETACHED", "1") != "0":
+        # Last module of the network: only output 0 is consumed (hrformer.py:776 / hrnet.py:441).  The reference still computes outputs
+        # 1..n-1; their only lasting effect is the running-statistics update of their BatchNorm layers in training mode.  They leave the
+        # critical path: eval mode skips them, training runs them without autograd on a detached side stream that is joined when the
+        # outermost dispatch.scope exits (they used to be three branches of a fork / join in front of the head: 164 us vs 70 us for output 0).
+        y0 = exchange_output(0, xs, fuse, training)
+        if training:
+            det = [t.detach() for t in xs]
+            dispatch.run_detached(lambda: [exchange_output(i, det, fuse, training) for i in range(1, n)], det)
+        return [y0]
     n_o = n if n_out is None else n_out
     return dispatch.parallel([(lambda ins, i=i: exchange_output(i, ins, fuse, training)) for i in range(n_o)], [list(xs)] * n_o)
 

@@ -1336,3 +1336,27 @@ def test_hrformer_without_relative_position_bias_vs_golden(golden):
     with torch.no_grad():
         out = bb(G(synth_input("norpe_bb", (1, 3, 64, 64))))
     assert rel_err(C(out), z["bb_out"]) < 3e-2
+
+
+def test_graph_replay_without_relative_position_bias_matches_eager():
+    """HRFormer(with_rpe=False) through the captured hipGraph step: the fused attention backward must not upload a reduction
+    table for the (constant, all-zero) bias table during capture; the replayed trajectory follows the eager one."""
+    from infantposeestimation_gaussianbias_amd import engine
+    from infantposeestimation_gaussianbias_amd.configs import get_config
+    from infantposeestimation_gaussianbias_amd.datasets import synthetic_batch
+    from infantposeestimation_gaussianbias_amd.models import PoseEstimator, hrformer
+    cfg = get_config("hrformer_small")
+    cfg.data.input_size, cfg.data.heatmap_size = (96, 128), (24, 32)
+    batches = [synthetic_batch(4, cfg.data.input_size, cfg.data.heatmap_size, 17, 2.0, DEV, seed=60 + i) for i in range(3)]
+    traj = {}
+    for mode in (False, True):
+        torch.manual_seed(0)
+        bb = hrformer.HRFormer(with_rpe=False, in_channels=3, drop_path_rate=0.0, stage2_num_channels=(32, 64), stage2_num_heads=(1, 2),
+                               stage3_num_channels=(32, 64, 128), stage3_num_heads=(1, 2, 4), stage4_num_channels=(32, 64, 128, 256),
+                               stage4_num_heads=(1, 2, 4, 8))
+        model = PoseEstimator.from_backbone(bb, 32, 17, "fusion", True).to(DEV)
+        assert not any("relative_position" in k for k in model.state_dict())
+        tr = engine.Trainer(model, cfg, iters_per_epoch=2, use_graph=mode, graph_warmup=2, graph_streams=mode)
+        traj[mode] = [float(tr.step(batches[i % 3])["loss"].detach()) for i in range(5)]
+        assert (tr._graph is not None) == mode
+    assert np.allclose(traj[False], traj[True], rtol=2e-3), traj

@@ -13,7 +13,7 @@ import logging
 import os
 import sys
 import time
-from datetime import datetime
+from datetime import datetime, timedelta
 
 import numpy as np
 import torch
@@ -110,7 +110,15 @@ def main(args):
             best_ap = max(best_ap, metrics["AP"])
             save_checkpoint(model, trainer, epoch, dict({k: float(v) for k, v in metrics.items()}, train_loss=float(loss)), out_dir, is_best=is_best)
         if world > 1 and ((epoch + 1) % cfg.train.val_interval == 0 or epoch == cfg.train.max_epochs - 1):
-            dist.barrier()          # the other ranks wait here, not inside the next epoch's first all-reduce (RCCL watchdog timeout)
+            # The other ranks wait for rank 0's validation on the HOST (a key in the rendezvous store), not inside a collective: a
+            # dist.barrier() or the next epoch's first all-reduce would sit enqueued for the whole validation and trip the RCCL
+            # watchdog timeout.  Unverified on hardware until a >= 2-GPU run exists (SCALE has been skipped so far).
+            store = dist.distributed_c10d._get_default_store()
+            key = f"pose/validated/{epoch}"
+            if rank == 0:
+                store.set(key, "1")
+            else:
+                store.wait([key], timedelta(hours=12))
     if world > 1:
         dist.destroy_process_group()
 

@@ -177,6 +177,53 @@ int pk_conv2d_affine_nhwc(const void* x, const void* w_packed, void* out, const 
                           const void* residual, int relu, int B, int Hs, int Ws, int Cin, int Cout, int ksize, int stride, int Ho,
                           int Wo, void* stream);
 int pk_conv_stats_tiles(int M);
+/* ---- Grouped launches (round 4): the exchange units (models/hrformer.py:420-491 == models/hrnet.py:157-227) are 2-12 small conv + BatchNorm
+ * layers per dependency level; each level runs as ONE launch per kernel family.  Descriptor arrays are HOST memory, read before the call
+ * returns (they travel in the kernel arguments); every pointer inside is a borrowed device pointer.  At most PK_GROUP_MAX members.       */
+#define PK_GROUP_MAX 12
+typedef struct PkConvDesc {        /* one pk_conv2d_nhwc (out_mode 0) or pk_conv2d_affine_nhwc problem                                   */
+    const void* x; const void* w; void* out;
+    float* stats;                  /* [pk_conv_stats_tiles(B*Ho*Wo)][2][Cout] partial statistics, or NULL                                */
+    const float* col_scale;        /* eval-mode BatchNorm folded into the epilogue (with bias = shift), or NULL                          */
+    const float* bias;
+    const void* res;               /* residual (affine form) or addend (data gradient), bf16, shape of out, or NULL                      */
+    int B, Hs, Ws, Cin, Cout, ksize, stride, dilated_input, Ho, Wo;
+    int act;                       /* 0 none, 3 ReLU after the residual add                                                              */
+} PkConvDesc;
+int pk_conv2d_group(const PkConvDesc* descs, int n, void* stream);
+typedef struct PkBnFwdDesc {       /* one pk_bn_train_fwd problem (finalize + apply in one pass; any row count)                          */
+    const void* raw; const float* stats_partial; const float* gamma; const float* beta;
+    float* running_mean; float* running_var; int64_t* num_batches_tracked;
+    const void* residual; void* y; float* save_mean; float* save_rstd;
+    int64_t rows; int tiles, C; float momentum, eps; int relu;
+} PkBnFwdDesc;
+int pk_bn_train_fwd_group(const PkBnFwdDesc* descs, int n, void* stream);
+typedef struct PkBnBwdDesc {       /* one pk_bn_bwd problem; partial: [pk_bn_bwd_group_blocks(rows)][2][C] floats                        */
+    const void* dy; const void* y_act; const void* raw; const float* save_mean; const float* save_rstd; const float* gamma;
+    float* partial; float* dgamma; float* dbeta; void* dx; void* dresidual;
+    int64_t rows; int C; int relu;  /* bit 0: mask by y_act > 0; bit 1: eval-mode statistics (no batch-mean terms)                          */
+} PkBnBwdDesc;
+int pk_bn_bwd_group_blocks(int64_t rows);
+int pk_bn_bwd_group(const PkBnBwdDesc* descs, int n, void* stream);
+typedef struct PkFuseDesc {        /* one pk_fuse_sum problem; mask_y (optional, shape of out): input 0 counts only where mask_y > 0 (the ReLU
+                                    * backward of a fused sum folded into the sum of input gradients)                                      */
+    const void* inputs[4]; int in_h[4]; int in_w[4]; int n_inputs;
+    void* out; const void* mask_y; int B, H, W, C, relu;
+} PkFuseDesc;
+int pk_fuse_sum_group(const PkFuseDesc* descs, int n, void* stream);
+typedef struct PkUpBwdDesc {       /* one pk_upsample_bilinear_bwd problem; mask_y (optional, shape of dy): dy counts only where mask_y > 0  */
+    const void* dy; const void* mask_y; void* dsrc; int B, H, W, Hs, Ws, C;
+} PkUpBwdDesc;
+int pk_upsample_bwd_group(const PkUpBwdDesc* descs, int n, void* stream);
+typedef struct PkWgradDesc {       /* weight-gradient SLABS of one 1x1 stride-1 or 3x3 stride-2 conv (all members of one kind): workspace =
+                                    * pk_wgrad_group_slices(...) x N x k*k x Cin floats, layout [S][N][k*k][Cin], reduced by pk_reduce_many */
+    const void* x; const void* grad_out; float* workspace;
+    int B, Hs, Ws, Ho, Wo, N, Cin, ksize, stride;
+} PkWgradDesc;
+int pk_wgrad_group_slices(int M, int N, int Cin, int ksize, int stride);
+int pk_wgrad_group(const PkWgradDesc* descs, int n, void* stream);
+int pk_sizeof_group_desc(int which);   /* sizeof of PkConvDesc (0), PkBnFwdDesc (1), PkBnBwdDesc (2), PkFuseDesc (3), PkUpBwdDesc (4), PkWgradDesc (5) */
+
 /* Rows of the [rows][2][Cout] partial-statistics buffer a pk_conv2d_nhwc launch with bf16 output and statistics writes for this geometry
  * (the 3x3 halo kernel emits one row per 64 padded positions; everything else pk_conv_stats_tiles(B*Ho*Wo)).  Replaces the per-call
  * `torch.var_mean` inside nn.BatchNorm2d of the reference (models/hrnet.py:24-52): pk_bn_finalize sums the rows it is given. */

@@ -181,8 +181,10 @@ __device__ __forceinline__ void igemm_epilogue_row8(const IgemmArgs& p, f32x4 lo
 // LEAN = 1: the token GEMMs of the HRFormer blocks only (linear rows with optional gather / scatter maps, bias, residual with a per-sample
 // scale, bf16 output) -- the convolution addressing, the activations, the fp32 / NCHW outputs and the statistics are compiled out.  The
 // full kernel is 27-30 KB of code; a small launch (100-900 workgroups, 1-4 K-steps) spends much of its few microseconds fetching it cold.
+// The kernel body takes its tile coordinates and grid shape as arguments: k_igemm2 passes blockIdx / gridDim, the GROUPED launch
+// k_igemm2g (below) cuts one 1-D grid into the tile grids of several independent problems.
 template <int BM, int BN, int WM, int WN, int BK, int LEAN = 0>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_igemm2(IgemmArgs p_in) {
+__device__ __forceinline__ void igemm2_body(const IgemmArgs& p_in, const int bid_x, const int bid_y, const int grid_x, const int grid_y) {
     IgemmArgs p = p_in;
     if (LEAN == 3) {
         // every feature of the epilogue, but the PLAIN addressing in the K loop: no dilated gather (stride-2 data gradients), no parity
@@ -219,13 +221,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
     // L2: with the plain mapping the two N-tiles of one pixel tile (same input!) and the halo-sharing neighbours of a
     // 3x3 conv land on different L2s (measured: 11x the input bytes cross the fabric for the 256->256 head conv).  Give
     // every XCD one contiguous chunk of the tile sequence, N-tile index fastest.
-    int mt = blockIdx.x, nt = blockIdx.y;
+    int mt = bid_x, nt = bid_y;
     {
-        const int G = gridDim.x * gridDim.y, L = blockIdx.x + gridDim.x * blockIdx.y;
+        const int G = grid_x * grid_y, L = bid_x + grid_x * bid_y;
         if ((G & 7) == 0 && p.xcd_remap) {
             const int tile = (L & 7) * (G >> 3) + (L >> 3);
-            mt = tile / (int)gridDim.y;
-            nt = tile - mt * (int)gridDim.y;
+            mt = tile / grid_y;
+            nt = tile - mt * grid_y;
         }
     }
     const int m0 = mt * BM, n0 = nt * BN;
@@ -679,6 +681,31 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k
             }
         }
     }
+}
+
+template <int BM, int BN, int WM, int WN, int BK, int LEAN = 0>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_igemm2(IgemmArgs p_in) {
+    igemm2_body<BM, BN, WM, WN, BK, LEAN>(p_in, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)gridDim.y);
+}
+
+// GROUPED launch (round 4): up to PK_GROUP_MAX independent convolutions / linear layers of ONE tile shape in one launch.  The exchange
+// units of HRNet / HRFormer (hrformer.py:420-491, hrnet.py:157-227) are 2-12 tiny conv + BatchNorm layers per level on 1 500 .. 50 000
+// pixels; as separate launches each paid ~10 us of fixed cost (dispatch ramp, cold code, first-tile latency, epilogue tail) for 1-3 us of
+// work, and the step time followed the NUMBER of launches (1 288 x 13 us = 17 ms).  The argument blocks travel BY VALUE in the kernel
+// arguments (no descriptor upload: the pointers change every step in eager mode); `first` is the prefix sum of the members' tile counts.
+struct IgemmGroup {
+    IgemmArgs a[PK_GROUP_MAX];
+    int first[PK_GROUP_MAX + 1];
+    int gy[PK_GROUP_MAX];
+    int n;
+};
+template <int BM, int BN, int WM, int WN, int BK, int LEAN>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) k_igemm2g(IgemmGroup g) {
+    const int L = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && L >= g.first[i + 1]) ++i;          // workgroup-uniform (scalar) search over <= 12 entries
+    const int local = L - g.first[i], gy = g.gy[i], gx = (g.first[i + 1] - g.first[i]) / gy;
+    igemm2_body<BM, BN, WM, WN, BK, LEAN>(g.a[i], local % gx, local / gx, gx, gy);
 }
 
 // ================================================================================================ ring kernel (head convs)
@@ -1437,6 +1464,65 @@ extern "C" int pk_conv2d_affine_nhwc(const void* x, const void* w_packed, void* 
     return igemm_launch(a, (hipStream_t)stream, "pk_conv2d_affine_nhwc");
 }
 
+// Grouped convolutions: n <= PK_GROUP_MAX members, each what one pk_conv2d_nhwc (train: bf16 output + statistics partials; data gradient:
+// dilated_input / addend) or pk_conv2d_affine_nhwc (col_scale / bias / residual / relu) call would do, all on the 128 x 32 tile of k_igemm2
+// (any Cout % 4 == 0; deep-K members share BK = 64 only when every member allows it).  Members must agree on `dilated_input`.
+extern "C" int pk_conv2d_group(const PkConvDesc* d, int n, void* stream) {
+    PK_REQUIRE(d && n > 0 && n <= PK_GROUP_MAX, "pk_conv2d_group: 1..%d members, got %d", PK_GROUP_MAX, n);
+    IgemmGroup g{};
+    bool k64 = true;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const PkConvDesc& c = d[i];
+        const int M = c.B * c.Ho * c.Wo;
+        int rc = check_common("pk_conv2d_group", c.x, c.w, c.out, M, c.Cout, c.Cin, c.Cout, 0);
+        if (rc) return rc;
+        PK_REQUIRE(c.ksize == 1 || c.ksize == 3, "pk_conv2d_group: ksize %d", c.ksize);
+        PK_REQUIRE(c.stride == 1 || (c.stride == 2 && !c.dilated_input), "pk_conv2d_group: stride %d", c.stride);
+        PK_REQUIRE(c.B > 0 && c.Hs > 0 && c.Ws > 0 && c.Ho > 0 && c.Wo > 0, "pk_conv2d_group: bad geometry");
+        PK_REQUIRE((c.dilated_input != 0) == (d[0].dilated_input != 0), "pk_conv2d_group: members must agree on dilated_input");
+        if (c.dilated_input) {
+            PK_REQUIRE(c.Ho <= 2 * c.Hs && c.Wo <= 2 * c.Ws && c.Ho >= 2 * c.Hs - 1 && c.Wo >= 2 * c.Ws - 1,
+                       "pk_conv2d_group: dilated geometry %dx%d <- %dx%d", c.Ho, c.Wo, c.Hs, c.Ws);
+        } else {
+            const int pad = c.ksize / 2;
+            PK_REQUIRE(c.Ho == (c.Hs + 2 * pad - c.ksize) / c.stride + 1 && c.Wo == (c.Ws + 2 * pad - c.ksize) / c.stride + 1,
+                       "pk_conv2d_group: output %dx%d does not match input %dx%d k=%d s=%d", c.Ho, c.Wo, c.Hs, c.Ws, c.ksize, c.stride);
+        }
+        PK_REQUIRE((int64_t)c.B * c.Hs * c.Ws * c.Cin < 0x3fffffffLL && (int64_t)c.Cout * c.ksize * c.ksize * c.Cin < 0x3fffffffLL,
+                   "pk_conv2d_group: input too large for 32-bit byte offsets");
+        PK_REQUIRE((c.Cout & 3) == 0, "pk_conv2d_group: Cout=%d must be a multiple of 4", c.Cout);
+        PK_REQUIRE(!(c.stats && (c.res || c.col_scale)), "pk_conv2d_group: statistics go with the plain bf16 output only");
+        PK_REQUIRE(c.act == 0 || c.act == 3, "pk_conv2d_group: act %d (0 none, 3 ReLU after the residual)", c.act);
+        IgemmArgs& a = g.a[i];
+        a.x = (const uint16_t*)c.x; a.w = (const uint16_t*)c.w; a.out = c.out; a.bias = c.bias; a.col_scale = c.col_scale;
+        a.stats = c.stats; a.res = (const uint16_t*)c.res;
+        a.M = M; a.N = c.Cout; a.Cin = c.Cin; a.T = c.ksize * c.ksize; a.Hs = c.Hs; a.Ws = c.Ws; a.Ho = c.Ho; a.Wo = c.Wo;
+        a.stride = c.stride; a.pad = c.ksize / 2; a.dilated = c.dilated_input ? 1 : 0; a.ldo = c.Cout; a.rows_per_sample = c.Ho * c.Wo;
+        a.act = c.act; a.out_mode = 0;
+        a.vec8 = (a.ldo % 8) == 0 && ((((uintptr_t)a.out | (uintptr_t)a.res) & 15) == 0);
+        a.xcd_remap = 0;            // (the remap assumes a grid of its own; these tensors fit in any one L2)
+        a.chunk_major = 0;
+        a.dil_group = a.dilated && a.T == 9 && !a.stats;
+        k64 = k64 && (a.Cin % 64) == 0 && a.T * a.Cin > 128;
+        g.gy[i] = (a.N + 31) / 32;
+        g.first[i] = total;
+        total += ((M + 127) / 128) * g.gy[i];
+    }
+    g.first[n] = total;
+    g.n = n;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)total), block(256);
+    if (d[0].dilated_input) {
+        if (k64) hipLaunchKernelGGL((k_igemm2g<128, 32, 4, 1, 64, 4>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((k_igemm2g<128, 32, 4, 1, 32, 4>), grid, block, 0, st, g);
+    } else {
+        if (k64) hipLaunchKernelGGL((k_igemm2g<128, 32, 4, 1, 64, 3>), grid, block, 0, st, g);
+        else hipLaunchKernelGGL((k_igemm2g<128, 32, 4, 1, 32, 3>), grid, block, 0, st, g);
+    }
+    return pk_launch_status("pk_conv2d_group");
+}
+
 extern "C" int pk_conv_stats_tiles(int M) { return (M + STAT_ROWS - 1) / STAT_ROWS; }
 // rows of the [rows][2][Cout] partial-statistics buffer that pk_conv2d_nhwc(bf16 output, statistics) writes for this geometry: the halo
 // kernel emits one row per 64 PADDED positions, every other kernel one per 128 output pixels (pk_bn_finalize sums whatever it is given)
@@ -1867,7 +1953,7 @@ template <int N> __device__ __forceinline__ void w4_wait_vm() { asm volatile("s_
 // and the output columns of the tile are the contiguous (tap, c) columns of dW[n][tap][c].  For the stem (Cin = 8: one chunk per tap)
 // all nine taps share one 128-column tile and one pass over G instead of nine.
 template <int TN, int TC, bool COLS = false>
-__global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
+__device__ __forceinline__ void wgrad4_body(const WgradArgs& p, const int bid) {
     constexpr int ST = (TN + TC <= 128) ? 8 : 4;                  // ring depth: 64 KB (64+64: 8 x 8 KB, 128+128: 4 x 16 KB), 48 KB otherwise
     constexpr int PG = TN / 64, PX = TC / 64, PER = PG + PX;      // 1 KiB DMA pieces per wave and step
     constexpr int RG = 512 / TN, RX = 512 / TC;                   // tile rows per piece
@@ -1876,7 +1962,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
     __shared__ __attribute__((aligned(1024))) uint16_t ring[ST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wc = wave & 1;
-    const int xcd = blockIdx.x & 7, k_in = blockIdx.x >> 3;
+    const int xcd = bid & 7, k_in = bid >> 3;
     const int zslice = xcd + 8 * (k_in / p.ntiles3), tile3 = k_in % p.ntiles3;
     if (zslice >= p.nslices3) return;            // padding workgroups of the last group of 8 slices (whole workgroup, before any barrier)
     const int ntile = tile3 / p.ctiles, ctile = tile3 - ntile * p.ctiles;
@@ -2013,6 +2099,22 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) {
                 if (n + r < p.N) p.bias_part[(size_t)zslice * p.N + n + r] = accb[a][r];
         }
     }
+}
+template <int TN, int TC, bool COLS = false>
+__global__ void __launch_bounds__(256, 2) k_wgrad4(WgradArgs p) { wgrad4_body<TN, TC, COLS>(p, (int)blockIdx.x); }
+// grouped form (round 4): the weight gradients of all the conv layers of one exchange-unit level in ONE launch; every member's block
+// range starts at a multiple of 8, so (local id & 7) is still the XCD a slice is dealt to
+struct WgradGroup {
+    WgradArgs a[PK_GROUP_MAX];
+    int first[PK_GROUP_MAX + 1];
+    int n;
+};
+template <int TN, int TC, bool COLS>
+__global__ void __launch_bounds__(256, 2) k_wgrad4g(WgradGroup g) {
+    const int L = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && L >= g.first[i + 1]) ++i;
+    wgrad4_body<TN, TC, COLS>(g.a[i], L - g.first[i]);
 }
 
 // k_wgrad4w: the single-tap kernel for operands whose rows are GATHERED through the 7x7 window partition and / or SCALED per sample
@@ -2571,6 +2673,55 @@ extern "C" int pk_wgrad_slices(int M, int N, int Cin, int ksize, int stride, int
     const int kind = wgrad4_kind(N, Cin, ksize, stride, Hs, Ws, flags);
     if (kind) return wgrad4_slices(wgrad4_rows(M, Hs, Ws, kind), N, Cin, kind);
     return wgrad_slices_old(M, N, Cin, ksize * ksize);
+}
+
+// ---- grouped weight gradients (slabs only; the caller reduces them with pk_reduce_many).  Two member kinds: 1x1 stride-1 convs (single
+// tap, 64 x 64 tiles) and 3x3 stride-2 convs (column form, 64 x 128 tiles); one fixed tile shape per kind so that one launch serves all.
+static inline int wgrad_group_kind(int ksize, int stride) { return (ksize == 1 && stride == 1) ? 1 : ((ksize == 3 && stride == 2) ? 3 : 0); }
+extern "C" int pk_wgrad_group_slices(int M, int N, int Cin, int ksize, int stride) {
+    const int kind = wgrad_group_kind(ksize, stride);
+    if (!kind) return 0;
+    const int tn = 64, tc = kind == 3 ? 128 : 64;
+    const int tiles = ((N + tn - 1) / tn) * (((kind == 3 ? 9 * Cin : Cin) + tc - 1) / tc);
+    int s = (256 + tiles - 1) / tiles;                    // ~one round of workgroups per member; slices of >= 512 rows
+    const int max_s = (M + 511) / 512;
+    if (s > max_s) s = max_s;
+    return s < 1 ? 1 : s;
+}
+extern "C" int pk_wgrad_group(const PkWgradDesc* d, int n, void* stream) {
+    PK_REQUIRE(d && n > 0 && n <= PK_GROUP_MAX, "pk_wgrad_group: 1..%d members, got %d", PK_GROUP_MAX, n);
+    WgradGroup g{};
+    const int kind = wgrad_group_kind(d[0].ksize, d[0].stride);
+    PK_SUPPORTED(kind != 0, "pk_wgrad_group: 1x1 stride-1 or 3x3 stride-2 convolutions only");
+    const int tn = 64, tc = kind == 3 ? 128 : 64;
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const PkWgradDesc& c = d[i];
+        PK_REQUIRE(c.x && c.grad_out && c.workspace, "pk_wgrad_group: null pointer");
+        PK_REQUIRE(wgrad_group_kind(c.ksize, c.stride) == kind, "pk_wgrad_group: members must be of one kind");
+        const int M = c.B * c.Ho * c.Wo;
+        PK_REQUIRE(M > 0 && c.N > 0 && c.Cin > 0 && c.Hs > 0 && c.Ws > 0, "pk_wgrad_group: bad sizes");
+        PK_SUPPORTED((c.Cin & 7) == 0 && (c.N & 7) == 0, "pk_wgrad_group: Cin=%d and N=%d must be multiples of 8", c.Cin, c.N);
+        PK_REQUIRE((int64_t)M * c.N < 0x3fffffffLL && (int64_t)c.B * c.Hs * c.Ws * c.Cin < 0x3fffffffLL, "pk_wgrad_group: tensor too large");
+        PK_REQUIRE(kind == 3 || (c.Ho == c.Hs && c.Wo == c.Ws), "pk_wgrad_group: stride-1 geometry");
+        WgradArgs& a = g.a[i];
+        a.x = (const uint16_t*)c.x; a.g = (const uint16_t*)c.grad_out; a.part = c.workspace; a.g_rows_per_sample = 1;
+        a.M = M; a.N = c.N; a.Cin = c.Cin; a.T = c.ksize * c.ksize; a.Hs = c.Hs; a.Ws = c.Ws; a.Ho = c.Ho; a.Wo = c.Wo; a.stride = c.stride;
+        a.pad = c.ksize / 2;
+        const int S = pk_wgrad_group_slices(M, c.N, c.Cin, c.ksize, c.stride);
+        a.ctiles = ((kind == 3 ? 9 * c.Cin : c.Cin) + tc - 1) / tc;
+        a.ntiles3 = ((c.N + tn - 1) / tn) * a.ctiles;
+        a.nslices3 = S;
+        a.m_per_slice = ((M + S - 1) / S + 31) / 32 * 32;
+        g.first[i] = total;
+        total += 8 * ((S + 7) / 8) * a.ntiles3;
+    }
+    g.first[n] = total;
+    g.n = n;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 3) hipLaunchKernelGGL((k_wgrad4g<64, 128, true>), dim3((unsigned)total), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_wgrad4g<64, 64, false>), dim3((unsigned)total), dim3(256), 0, st, g);
+    return pk_launch_status("pk_wgrad_group");
 }
 
 extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspace, float* dw, float* dbias, int n_bias,

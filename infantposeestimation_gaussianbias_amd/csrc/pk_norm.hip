@@ -178,14 +178,14 @@ extern "C" int pk_bn_act(const void* x, const float* scale, const float* shift, 
 // save_rstd and the running statistics.  One launch (~7 us of fixed cost on a latency-bound chain) less per layer.
 #define BNS_MAX_TILES 128
 #define BNS_CG 32
-__global__ void __launch_bounds__(256) k_bn_act_fin(const uint4* __restrict__ x, const float* __restrict__ part, int tiles, int C, float count,
-                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
-                                                    float* __restrict__ run_var, long long* __restrict__ nbt, float momentum, float eps,
-                                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, const uint4* __restrict__ res,
-                                                    uint4* __restrict__ y, int rows, int rows_per_block, int relu) {
+__device__ __forceinline__ void bn_act_fin_body(const uint4* __restrict__ x, const float* __restrict__ part, int tiles, int C, float count,
+                                                const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                float* __restrict__ run_var, long long* __restrict__ nbt, float momentum, float eps,
+                                                float* __restrict__ mean_out, float* __restrict__ rstd_out, const uint4* __restrict__ res,
+                                                uint4* __restrict__ y, int rows, int rows_per_block, int relu, const int cg, const int rb) {
     __shared__ double shs[8][BNS_CG], shq[8][BNS_CG];
     __shared__ float s_scale[BNS_CG], s_shift[BNS_CG];
-    const int cg = blockIdx.x, rb = blockIdx.y, c0 = cg * BNS_CG;
+    const int c0 = cg * BNS_CG;
     {
         const int cl = threadIdx.x & (BNS_CG - 1), pl = threadIdx.x >> 5, c = c0 + cl;
         double sm = 0.0, sq = 0.0;
@@ -248,6 +248,58 @@ __global__ void __launch_bounds__(256) k_bn_act_fin(const uint4* __restrict__ x,
         y[i] = pack8(v);
     }
 }
+__global__ void __launch_bounds__(256) k_bn_act_fin(const uint4* __restrict__ x, const float* __restrict__ part, int tiles, int C, float count,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
+                                                    float* __restrict__ run_var, long long* __restrict__ nbt, float momentum, float eps,
+                                                    float* __restrict__ mean_out, float* __restrict__ rstd_out, const uint4* __restrict__ res,
+                                                    uint4* __restrict__ y, int rows, int rows_per_block, int relu) {
+    bn_act_fin_body(x, part, tiles, C, count, gamma, beta, run_mean, run_var, nbt, momentum, eps, mean_out, rstd_out, res, y, rows, rows_per_block,
+                    relu, (int)blockIdx.x, (int)blockIdx.y);
+}
+// grouped form: up to PK_GROUP_MAX BatchNorm layers (any row count: every workgroup re-derives the statistics of its 32 channels)
+struct BnFwdGroup {
+    PkBnFwdDesc d[PK_GROUP_MAX];
+    int first[PK_GROUP_MAX + 1], ncg[PK_GROUP_MAX], rpb[PK_GROUP_MAX];
+    int n;
+};
+__global__ void __launch_bounds__(256) k_bn_act_fin_g(BnFwdGroup g) {
+    const int L = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && L >= g.first[i + 1]) ++i;
+    const PkBnFwdDesc& d = g.d[i];
+    const int local = L - g.first[i], ncg = g.ncg[i];
+    bn_act_fin_body((const uint4*)d.raw, d.stats_partial, d.tiles, d.C, (float)d.rows, d.gamma, d.beta, d.running_mean, d.running_var,
+                    (long long*)d.num_batches_tracked, d.momentum, d.eps, d.save_mean, d.save_rstd, (const uint4*)d.residual, (uint4*)d.y,
+                    (int)d.rows, g.rpb[i], d.relu, local % ncg, local / ncg);
+}
+static inline void bn_fin_grid(int64_t rows, int C, int& ncg, int& nrb, int& rpb) {
+    ncg = (C + BNS_CG - 1) / BNS_CG;
+    nrb = (int)((rows + 127) / 128);                       // >= 128 rows per workgroup, ~256 workgroups in all
+    const int want = (256 + ncg - 1) / ncg;
+    if (nrb > want) nrb = want;
+    if (nrb < 1) nrb = 1;
+    rpb = (int)((rows + nrb - 1) / nrb);
+}
+extern "C" int pk_bn_train_fwd_group(const PkBnFwdDesc* d, int n, void* stream) {
+    PK_REQUIRE(d && n > 0 && n <= PK_GROUP_MAX, "pk_bn_train_fwd_group: 1..%d members, got %d", PK_GROUP_MAX, n);
+    BnFwdGroup g{};
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const PkBnFwdDesc& c = d[i];
+        PK_REQUIRE(c.raw && c.stats_partial && c.gamma && c.beta && c.y && c.save_mean && c.save_rstd, "pk_bn_train_fwd_group: null pointer");
+        PK_REQUIRE(c.tiles > 0 && c.C > 0 && (c.C & 7) == 0 && c.rows > 0 && c.rows < (1 << 30), "pk_bn_train_fwd_group: bad sizes");
+        g.d[i] = c;
+        int nrb;
+        bn_fin_grid(c.rows, c.C, g.ncg[i], nrb, g.rpb[i]);
+        g.first[i] = total;
+        total += g.ncg[i] * nrb;
+    }
+    g.first[n] = total;
+    g.n = n;
+    hipLaunchKernelGGL(k_bn_act_fin_g, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, g);
+    return pk_launch_status("pk_bn_train_fwd_group");
+}
+
 // Train-mode BatchNorm forward from the conv epilogue's partial statistics: finalize + apply.  One fused launch for small tensors, the
 // two kernels above otherwise.  `scale` / `shift`: [C] workspaces of the two-launch path.
 extern "C" int pk_bn_train_fwd(const void* raw, const float* stats_partial, int tiles, int C, int64_t rows, const float* gamma,
@@ -281,10 +333,10 @@ extern "C" int pk_bn_train_fwd(const void* raw, const float* stats_partial, int 
 // bandwidth-bound kernels more than the saved 2 bytes per element.)
 // Block = 256 threads = (256/cchunks) row lanes x cchunks channel chunks; partial[block][2][C].
 #define BNR_MAXC 1024
-__global__ void __launch_bounds__(256) k_bn_bwd_reduce(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
-                                                       const uint4* __restrict__ raw, const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, float* __restrict__ part, int64_t rows, int C,
-                                                       int relu, int rows_per_block) {
+__device__ __forceinline__ void bn_bwd_reduce_body(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
+                                                   const uint4* __restrict__ raw, const float* __restrict__ mean,
+                                                   const float* __restrict__ rstd, float* __restrict__ part, int64_t rows, int C,
+                                                   int relu, int rows_per_block, const int bid) {
     __shared__ float sh[256 * 16];
     const int cchunks = C / 8, rlanes = 256 / cchunks;
     const int cc = threadIdx.x % cchunks, rl = threadIdx.x / cchunks;
@@ -295,7 +347,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const uint4* __restrict__
         mu[j] = mean[cc * 8 + j];
         rs[j] = rstd[cc * 8 + j];
     }
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(rows, r0 + (int64_t)rows_per_block);
+    const int64_t r0 = (int64_t)bid * rows_per_block, r1 = min(rows, r0 + (int64_t)rows_per_block);
     if (rl < rlanes) {
         for (int64_t r = r0 + rl; r < r1; r += rlanes) {
             const size_t i = (size_t)r * cchunks + cc;
@@ -327,13 +379,19 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const uint4* __restrict__
                 a2[j] += sh[t * 16 + 8 + j];
             }
         }
-        float* dst = part + (size_t)blockIdx.x * 2 * C;
+        float* dst = part + (size_t)bid * 2 * C;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             dst[threadIdx.x * 8 + j] = a1[j];
             dst[C + threadIdx.x * 8 + j] = a2[j];
         }
     }
+}
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
+                                                       const uint4* __restrict__ raw, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, float* __restrict__ part, int64_t rows, int C,
+                                                       int relu, int rows_per_block) {
+    bn_bwd_reduce_body(dy, yact, raw, mean, rstd, part, rows, C, relu, rows_per_block, (int)blockIdx.x);
 }
 // Backward, pass 2: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); optional d_residual = g
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
@@ -379,15 +437,15 @@ extern "C" int pk_bn_bwd_blocks(int64_t rows) {
 }
 // Small tensors: pass 2 with the partial-sum reduction folded in (see k_bn_act_fin): each workgroup owns 32 channels x a block of rows,
 // reduces partial[nb][2][C] for its channels (8 lanes, fixed order, double), row block 0 writes dbeta / dgamma; then dx (and dres).
-__global__ void __launch_bounds__(256) k_bn_bwd_apply_fin(const uint4* __restrict__ dy, const uint4* __restrict__ yact, const uint4* __restrict__ raw,
-                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                          const float* __restrict__ gamma, const float* __restrict__ part, int nb,
-                                                          float inv_count, float* __restrict__ dbeta, float* __restrict__ dgamma,
-                                                          uint4* __restrict__ dx, uint4* __restrict__ dres, int rows, int rows_per_block, int C,
-                                                          int relu) {
+__device__ __forceinline__ void bn_bwd_apply_fin_body(const uint4* __restrict__ dy, const uint4* __restrict__ yact, const uint4* __restrict__ raw,
+                                                      const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                      const float* __restrict__ gamma, const float* __restrict__ part, int nb,
+                                                      float inv_count, float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                      uint4* __restrict__ dx, uint4* __restrict__ dres, int rows, int rows_per_block, int C,
+                                                      int relu, const int cg, const int rb) {
     __shared__ double sh1[8][BNS_CG], sh2[8][BNS_CG];
     __shared__ float s_1[BNS_CG], s_2[BNS_CG];
-    const int cg = blockIdx.x, rb = blockIdx.y, c0 = cg * BNS_CG;
+    const int c0 = cg * BNS_CG;
     {
         const int cl = threadIdx.x & (BNS_CG - 1), pl = threadIdx.x >> 5, c = c0 + cl;
         double a = 0.0, b = 0.0;
@@ -446,6 +504,75 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_fin(const uint4* __restric
         if (dres) dres[i] = pack8(g);
     }
 }
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_fin(const uint4* __restrict__ dy, const uint4* __restrict__ yact, const uint4* __restrict__ raw,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          const float* __restrict__ gamma, const float* __restrict__ part, int nb,
+                                                          float inv_count, float* __restrict__ dbeta, float* __restrict__ dgamma,
+                                                          uint4* __restrict__ dx, uint4* __restrict__ dres, int rows, int rows_per_block, int C,
+                                                          int relu) {
+    bn_bwd_apply_fin_body(dy, yact, raw, mean, rstd, gamma, part, nb, inv_count, dbeta, dgamma, dx, dres, rows, rows_per_block, C, relu,
+                          (int)blockIdx.x, (int)blockIdx.y);
+}
+// grouped backward: ONE reduce launch + ONE apply launch for up to PK_GROUP_MAX BatchNorm layers
+struct BnBwdGroup {
+    PkBnBwdDesc d[PK_GROUP_MAX];
+    int first_r[PK_GROUP_MAX + 1], first_a[PK_GROUP_MAX + 1];
+    int nb[PK_GROUP_MAX], rpb_r[PK_GROUP_MAX], ncg[PK_GROUP_MAX], rpb_a[PK_GROUP_MAX];
+    int n;
+};
+__global__ void __launch_bounds__(256) k_bn_bwd_reduce_g(BnBwdGroup g) {
+    const int L = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && L >= g.first_r[i + 1]) ++i;
+    const PkBnBwdDesc& d = g.d[i];
+    bn_bwd_reduce_body((const uint4*)d.dy, (const uint4*)d.y_act, (const uint4*)d.raw, d.save_mean, d.save_rstd, d.partial, d.rows, d.C, d.relu & 1,
+                       g.rpb_r[i], L - g.first_r[i]);
+}
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_fin_g(BnBwdGroup g) {
+    const int L = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && L >= g.first_a[i + 1]) ++i;
+    const PkBnBwdDesc& d = g.d[i];
+    const int local = L - g.first_a[i], ncg = g.ncg[i];
+    bn_bwd_apply_fin_body((const uint4*)d.dy, (const uint4*)d.y_act, (const uint4*)d.raw, d.save_mean, d.save_rstd, d.gamma, d.partial, g.nb[i],
+                          (d.relu & 2) ? 0.f : 1.f / (float)d.rows, d.dbeta, d.dgamma, (uint4*)d.dx, (uint4*)d.dresidual, (int)d.rows, g.rpb_a[i],
+                          d.C, d.relu & 1, local % ncg, local / ncg);
+}
+// partial rows [blocks][2][C] of a member of pk_bn_bwd_group: the small-tensor rule of pk_bn_bwd where it applies (same sums bit for bit)
+extern "C" int pk_bn_bwd_group_blocks(int64_t rows) {
+    if (bn_bwd_small(rows)) return pk_bn_bwd_blocks(rows);
+    const int64_t nb = (rows + 127) / 128;
+    return (int)(nb > 256 ? 256 : nb);
+}
+extern "C" int pk_bn_bwd_group(const PkBnBwdDesc* d, int n, void* stream) {
+    PK_REQUIRE(d && n > 0 && n <= PK_GROUP_MAX, "pk_bn_bwd_group: 1..%d members, got %d", PK_GROUP_MAX, n);
+    BnBwdGroup g{};
+    int tr = 0, ta = 0;
+    for (int i = 0; i < n; ++i) {
+        const PkBnBwdDesc& c = d[i];
+        PK_REQUIRE(c.dy && c.raw && c.save_mean && c.save_rstd && c.gamma && c.partial && c.dgamma && c.dbeta && c.dx, "pk_bn_bwd_group: null pointer");
+        PK_REQUIRE(!(c.relu & 1) || c.y_act, "pk_bn_bwd_group: relu needs the activated output");
+        PK_REQUIRE(c.rows > 0 && c.rows < (1 << 30) && c.C > 0 && (c.C & 7) == 0, "pk_bn_bwd_group: bad sizes");
+        PK_SUPPORTED(c.C <= BNR_MAXC && c.C / 8 <= 256, "pk_bn_bwd_group: C=%d too large", c.C);
+        g.d[i] = c;
+        g.nb[i] = pk_bn_bwd_group_blocks(c.rows);
+        g.rpb_r[i] = (int)((c.rows + g.nb[i] - 1) / g.nb[i]);
+        int nrb;
+        bn_fin_grid(c.rows, c.C, g.ncg[i], nrb, g.rpb_a[i]);
+        g.first_r[i] = tr;
+        g.first_a[i] = ta;
+        tr += g.nb[i];
+        ta += g.ncg[i] * nrb;
+    }
+    g.first_r[n] = tr;
+    g.first_a[n] = ta;
+    g.n = n;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(k_bn_bwd_reduce_g, dim3((unsigned)tr), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(k_bn_bwd_apply_fin_g, dim3((unsigned)ta), dim3(256), 0, st, g);
+    return pk_launch_status("pk_bn_bwd_group");
+}
+
 extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* save_mean, const float* save_rstd,
                          const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
                          int64_t rows, int C, int relu, void* stream) {
@@ -777,7 +904,7 @@ extern "C" int pk_colsum_bf16(const void* g, const int32_t* rowmap, const float*
 // out = relu?( sum_i up_i(x_i) ): every input is NHWC bf16 with the same C; input i has spatial size (H>>s_i, W>>s_i)
 // ... in general (Hi, Wi) and is bilinearly up-sampled (align_corners=False) to (H, W) when smaller.
 struct FuseIn { const uint16_t* p; int H, W; };
-struct FuseArgs { FuseIn in[4]; int n; uint16_t* out; int B, H, W, C, relu; };
+struct FuseArgs { FuseIn in[4]; int n; uint16_t* out; int B, H, W, C, relu; const uint16_t* mask_y; };   // mask_y: term 0 counts only where mask_y > 0
 __device__ __forceinline__ void bil_taps(int o, int n_in, int n_out, int& i0, int& i1, float& f) {
     float s = ((float)o + 0.5f) * ((float)n_in / (float)n_out) - 0.5f;
     s = fmaxf(s, 0.f);
@@ -785,11 +912,11 @@ __device__ __forceinline__ void bil_taps(int o, int n_in, int n_out, int& i0, in
     i1 = min(i0 + 1, n_in - 1);
     f = s - (float)i0;
 }
-__global__ void __launch_bounds__(256) k_fuse_sum(FuseArgs a) {
+__device__ __forceinline__ void fuse_sum_body(const FuseArgs& a, const int bid, const int nblocks) {
     const int cchunks = a.C / 8;
     const size_t chunks = (size_t)a.B * a.H * a.W * cchunks;
     const float inv_c = 1.f / (float)cchunks, inv_w = 1.f / (float)a.W, inv_h = 1.f / (float)a.H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
+    for (size_t i = (size_t)bid * blockDim.x + threadIdx.x; i < chunks; i += (size_t)nblocks * blockDim.x) {
         // (32-bit index arithmetic: five size_t divisions were ~300 VALU instructions per 16-byte output chunk)
         const uint32_t i32 = (uint32_t)i;
         const bool f24 = chunks < (1u << 24);
@@ -804,6 +931,12 @@ __global__ void __launch_bounds__(256) k_fuse_sum(FuseArgs a) {
             float v[8];
             if (in.H == a.H && in.W == a.W) {
                 unpack8(*reinterpret_cast<const uint4*>(in.p + (((size_t)b * a.H + y) * a.W + x) * a.C + cc * 8), v);
+                if (k == 0 && a.mask_y) {         // relu backward folded into the sum of input gradients: g = dy * (y > 0)
+                    float m[8];
+                    unpack8(*reinterpret_cast<const uint4*>(a.mask_y + i * 8), m);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
+                }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) acc[j] += v[j];
             } else {
@@ -829,6 +962,49 @@ __global__ void __launch_bounds__(256) k_fuse_sum(FuseArgs a) {
         *reinterpret_cast<uint4*>(a.out + i * 8) = pack8(acc);
     }
 }
+__global__ void __launch_bounds__(256) k_fuse_sum(FuseArgs a) { fuse_sum_body(a, (int)blockIdx.x, (int)gridDim.x); }
+struct FuseGroup {
+    FuseArgs a[PK_GROUP_MAX];
+    int first[PK_GROUP_MAX + 1];
+    int n;
+};
+__global__ void __launch_bounds__(256) k_fuse_sum_g(FuseGroup g) {
+    const int L = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && L >= g.first[i + 1]) ++i;
+    fuse_sum_body(g.a[i], L - g.first[i], g.first[i + 1] - g.first[i]);
+}
+static int fuse_args_from(const PkFuseDesc& c, FuseArgs& a, const char* who) {
+    PK_REQUIRE(c.out && c.n_inputs >= 1 && c.n_inputs <= 4, "%s: bad argument", who);
+    PK_REQUIRE(c.B > 0 && c.H > 0 && c.W > 0 && c.C > 0 && (c.C & 7) == 0, "%s: bad shape", who);
+    for (int i = 0; i < c.n_inputs; ++i) {
+        PK_REQUIRE(c.inputs[i] && c.in_h[i] > 0 && c.in_w[i] > 0 && c.in_h[i] <= c.H && c.in_w[i] <= c.W, "%s: input %d shape", who, i);
+        a.in[i] = FuseIn{(const uint16_t*)c.inputs[i], c.in_h[i], c.in_w[i]};
+    }
+    PK_REQUIRE(!c.mask_y || (c.in_h[0] == c.H && c.in_w[0] == c.W), "%s: the masked term must have the output's size", who);
+    a.n = c.n_inputs; a.out = (uint16_t*)c.out; a.B = c.B; a.H = c.H; a.W = c.W; a.C = c.C; a.relu = c.relu; a.mask_y = (const uint16_t*)c.mask_y;
+    PK_SUPPORTED((size_t)c.B * c.H * c.W * (c.C / 8) < 0xffffffffull, "%s: tensor too large for 32-bit chunk indices", who);
+    return PK_OK;
+}
+// up to PK_GROUP_MAX sums (the outputs of one exchange unit, or the input-gradient sums of its backward) in ONE launch
+extern "C" int pk_fuse_sum_group(const PkFuseDesc* d, int n, void* stream) {
+    PK_REQUIRE(d && n > 0 && n <= PK_GROUP_MAX, "pk_fuse_sum_group: 1..%d members, got %d", PK_GROUP_MAX, n);
+    FuseGroup g{};
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        int rc = fuse_args_from(d[i], g.a[i], "pk_fuse_sum_group");
+        if (rc) return rc;
+        const size_t chunks = (size_t)d[i].B * d[i].H * d[i].W * (d[i].C / 8);
+        size_t gb = (chunks + 255) / 256;
+        if (gb > 2048) gb = 2048;
+        g.first[i] = total;
+        total += (int)gb;
+    }
+    g.first[n] = total;
+    g.n = n;
+    hipLaunchKernelGGL(k_fuse_sum_g, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, g);
+    return pk_launch_status("pk_fuse_sum_group");
+}
 extern "C" int pk_fuse_sum(const void* const* inputs, const int* in_h, const int* in_w, int n_inputs, void* out, int B, int H, int W,
                            int C, int relu, void* stream) {
     PK_REQUIRE(inputs && in_h && in_w && out && n_inputs >= 1 && n_inputs <= 4, "pk_fuse_sum: bad argument");
@@ -838,7 +1014,7 @@ extern "C" int pk_fuse_sum(const void* const* inputs, const int* in_h, const int
         PK_REQUIRE(inputs[i] && in_h[i] > 0 && in_w[i] > 0 && in_h[i] <= H && in_w[i] <= W, "pk_fuse_sum: input %d shape", i);
         a.in[i] = FuseIn{(const uint16_t*)inputs[i], in_h[i], in_w[i]};
     }
-    a.n = n_inputs; a.out = (uint16_t*)out; a.B = B; a.H = H; a.W = W; a.C = C; a.relu = relu;
+    a.n = n_inputs; a.out = (uint16_t*)out; a.B = B; a.H = H; a.W = W; a.C = C; a.relu = relu; a.mask_y = nullptr;
     const size_t chunks = (size_t)B * H * W * (C / 8);
     PK_SUPPORTED(chunks < 0xffffffffull, "pk_fuse_sum: tensor too large for 32-bit chunk indices");
     size_t gb = (chunks + 255) / 256;
@@ -850,15 +1026,15 @@ extern "C" int pk_fuse_sum(const void* const* inputs, const int* in_h, const int
 // Backward of the bilinear up-sampling (gather form, deterministic): dsrc[b][ys][xs][c] = sum over the output pixels
 // whose taps touch (ys,xs) of weight * dy.  `dy` is the (already relu-masked) gradient at the fused resolution.
 template <int SPLIT>   // lanes that share one output chunk (each takes every SPLIT-th row of the gather window)
-__global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dsrc, int B, int H, int W,
-                                                      int Hs, int Ws, int C) {
+__device__ __forceinline__ void upsample_bwd_body(const uint16_t* __restrict__ dy, const uint16_t* __restrict__ mask_y, uint16_t* __restrict__ dsrc,
+                                                  int B, int H, int W, int Hs, int Ws, int C, const int bid, const int nblocks) {
     const int cchunks = C / 8;
     const size_t chunks = (size_t)B * Hs * Ws * cchunks;
     const int ry = (H + Hs - 1) / Hs, rx = (W + Ws - 1) / Ws;
     const int sub = threadIdx.x % SPLIT;
-    const size_t groups_per_grid = (size_t)gridDim.x * blockDim.x / SPLIT;
+    const size_t groups_per_grid = (size_t)nblocks * blockDim.x / SPLIT;
     const size_t n_iter = (chunks + groups_per_grid - 1) / groups_per_grid;          // uniform trip count: all lanes reach the shuffles
-    size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) / SPLIT;
+    size_t i = ((size_t)bid * blockDim.x + threadIdx.x) / SPLIT;
     for (size_t it = 0; it < n_iter; ++it, i += groups_per_grid) {
         const bool on = i < chunks;
         const size_t ii = on ? i : 0;
@@ -894,6 +1070,12 @@ __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict
                     if (wx == 0.f) continue;
                     float v[8];
                     unpack8(*reinterpret_cast<const uint4*>(dy + (((size_t)b * H + oy) * W + ox) * C + cc * 8), v);
+                    if (mask_y) {                 // relu backward of the fused sum folded in: the gradient counts only where y > 0
+                        float m[8];
+                        unpack8(*reinterpret_cast<const uint4*>(mask_y + (((size_t)b * H + oy) * W + ox) * C + cc * 8), m);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = m[j] > 0.f ? v[j] : 0.f;
+                    }
 #pragma unroll
                     for (int j = 0; j < 8; ++j) acc[j] += wy * wx * v[j];
                 }
@@ -903,13 +1085,73 @@ __global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict
         if (on && sub == 0) *reinterpret_cast<uint4*>(dsrc + i * 8) = pack8(acc);
     }
 }
+template <int SPLIT>
+__global__ void __launch_bounds__(256) k_upsample_bwd(const uint16_t* __restrict__ dy, uint16_t* __restrict__ dsrc, int B, int H, int W,
+                                                      int Hs, int Ws, int C) {
+    upsample_bwd_body<SPLIT>(dy, nullptr, dsrc, B, H, W, Hs, Ws, C, (int)blockIdx.x, (int)gridDim.x);
+}
+static inline int upsample_split(int H, int Hs, size_t chunks) {
+    const int ry = (H + Hs - 1) / Hs;
+    // few output chunks with a tall gather window (scale 4 / 8): spread the window rows over 4 / 16 lanes per chunk
+    return (ry >= 8 && chunks < (1u << 20)) ? 16 : ((ry >= 4 && chunks < (1u << 20)) ? 4 : 1);
+}
+struct UpBwdGroup {
+    PkUpBwdDesc d[PK_GROUP_MAX];
+    int first[PK_GROUP_MAX + 1], split[PK_GROUP_MAX];
+    int n;
+};
+__global__ void __launch_bounds__(256) k_upsample_bwd_g(UpBwdGroup g) {
+    const int L = (int)blockIdx.x;
+    int i = 0;
+    while (i + 1 < g.n && L >= g.first[i + 1]) ++i;
+    const PkUpBwdDesc& d = g.d[i];
+    const int bid = L - g.first[i], nb = g.first[i + 1] - g.first[i], sp = g.split[i];
+    const uint16_t* dy = (const uint16_t*)d.dy;
+    const uint16_t* my = (const uint16_t*)d.mask_y;
+    uint16_t* ds = (uint16_t*)d.dsrc;
+    if (sp == 16) upsample_bwd_body<16>(dy, my, ds, d.B, d.H, d.W, d.Hs, d.Ws, d.C, bid, nb);
+    else if (sp == 4) upsample_bwd_body<4>(dy, my, ds, d.B, d.H, d.W, d.Hs, d.Ws, d.C, bid, nb);
+    else upsample_bwd_body<1>(dy, my, ds, d.B, d.H, d.W, d.Hs, d.Ws, d.C, bid, nb);
+}
+// the up-sampling backward of every up-route of one exchange unit in ONE launch; mask_y (optional) folds the fused sum's ReLU backward in
+extern "C" int pk_upsample_bwd_group(const PkUpBwdDesc* d, int n, void* stream) {
+    PK_REQUIRE(d && n > 0 && n <= PK_GROUP_MAX, "pk_upsample_bwd_group: 1..%d members, got %d", PK_GROUP_MAX, n);
+    UpBwdGroup g{};
+    int total = 0;
+    for (int i = 0; i < n; ++i) {
+        const PkUpBwdDesc& c = d[i];
+        PK_REQUIRE(c.dy && c.dsrc && c.B > 0 && c.H >= c.Hs && c.W >= c.Ws && c.Hs > 0 && c.Ws > 0 && c.C > 0 && (c.C & 7) == 0,
+                   "pk_upsample_bwd_group: bad argument");
+        const size_t chunks = (size_t)c.B * c.Hs * c.Ws * (c.C / 8);
+        PK_SUPPORTED(chunks < 0xffffffffull, "pk_upsample_bwd_group: tensor too large for 32-bit chunk indices");
+        g.d[i] = c;
+        g.split[i] = upsample_split(c.H, c.Hs, chunks);
+        size_t gb = (chunks * g.split[i] + 255) / 256;
+        if (gb > 2048) gb = 2048;
+        g.first[i] = total;
+        total += (int)gb;
+    }
+    g.first[n] = total;
+    g.n = n;
+    hipLaunchKernelGGL(k_upsample_bwd_g, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, g);
+    return pk_launch_status("pk_upsample_bwd_group");
+}
+extern "C" int pk_sizeof_group_desc(int which) {
+    switch (which) {
+        case 0: return (int)sizeof(PkConvDesc);
+        case 1: return (int)sizeof(PkBnFwdDesc);
+        case 2: return (int)sizeof(PkBnBwdDesc);
+        case 3: return (int)sizeof(PkFuseDesc);
+        case 4: return (int)sizeof(PkUpBwdDesc);
+        case 5: return (int)sizeof(PkWgradDesc);
+        default: return -1;
+    }
+}
 extern "C" int pk_upsample_bilinear_bwd(const void* dy, void* dsrc, int B, int H, int W, int Hs, int Ws, int C, void* stream) {
     PK_REQUIRE(dy && dsrc && B > 0 && H >= Hs && W >= Ws && Hs > 0 && Ws > 0 && C > 0 && (C & 7) == 0, "pk_upsample_bilinear_bwd: bad argument");
     const size_t chunks = (size_t)B * Hs * Ws * (C / 8);
     PK_SUPPORTED(chunks < 0xffffffffull, "pk_upsample_bilinear_bwd: tensor too large for 32-bit chunk indices");
-    const int ry = (H + Hs - 1) / Hs;
-    // few output chunks with a tall gather window (scale 4 / 8): spread the window rows over 4 / 16 lanes per chunk
-    const int split = (ry >= 8 && chunks < (1u << 20)) ? 16 : ((ry >= 4 && chunks < (1u << 20)) ? 4 : 1);
+    const int split = upsample_split(H, Hs, chunks);
     size_t gb = (chunks * split + 255) / 256;
     if (gb > 4096) gb = 4096;
     if (split == 16)

@@ -77,28 +77,85 @@ def collate_records(samples: List[Dict]) -> List[Dict]:
 class DeviceBatcher:
     """Iterates a loader of record lists and yields the reference's batch dict (coco_dataset.py:169-183) with everything on the device:
     `img` (B,3,H,W) fp32 normalised (+ `img_nhwc8`, the same pixels as bf16 8-channel NHWC = the stem's input), `target`, `target_weight`
-    from the T1 kernel, `keypoints`, `keypoints_visible`, `meta`."""
+    from the T1 kernel, `keypoints`, `keypoints_visible`, `meta`.
 
-    def __init__(self, loader, cfg, device="cuda"):
+    Prefetch (the role of the reference's DataLoader workers + pin_memory, coco_dataset.py:253-306): batch n + 1 is staged into a pinned
+    buffer, copied, cropped / normalised (pk_affine_crop_normalize) and turned into targets (pk_gaussian_target) on a SIDE stream while the
+    consumer's stream runs step n; handing a batch out costs one event wait.  `prefetch=False` does the same work on the consumer's stream."""
+
+    def __init__(self, loader, cfg, device="cuda", prefetch=True, nchw=True):
         self.loader, self.cfg, self.device = loader, cfg, torch.device(device)
-        self.cropper = DeviceCropper(cfg.data.input_size, device)
+        self.cropper = DeviceCropper(cfg.data.input_size, device, nchw=nchw)
         self.dataset = getattr(loader, "dataset", None)
+        self.prefetch = prefetch and torch.cuda.is_available() and self.device.type == "cuda"
+        self._stream = torch.cuda.Stream(device=self.device) if self.prefetch else None
+        self._kp_pinned = [None, None]
+        self._kp_ev = [None, None]
+        self._kp_slot = 0
 
     def __len__(self):
         return len(self.loader)
 
-    def __iter__(self):
+    def _keypoints_to_device(self, samples):
+        """keypoints + visibility through a small pinned buffer (a pageable .to(device) would block the host behind the side stream)."""
+        kp = np.stack([s["keypoints"] for s in samples]).astype(np.float32)
+        vis = np.stack([s["keypoints_visible"] for s in samples]).astype(np.float32)
+        both = np.concatenate([kp.reshape(-1), vis.reshape(-1)])
+        if not torch.cuda.is_available():
+            t = torch.from_numpy(both).to(self.device)
+        else:
+            i = self._kp_slot = self._kp_slot ^ 1
+            if self._kp_ev[i] is not None:
+                self._kp_ev[i].synchronize()
+            if self._kp_pinned[i] is None or self._kp_pinned[i].numel() < both.size:
+                self._kp_pinned[i] = torch.empty(both.size, dtype=torch.float32).pin_memory()
+            self._kp_pinned[i][:both.size] = torch.from_numpy(both)
+            t = self._kp_pinned[i][:both.size].to(self.device, non_blocking=True)
+            self._kp_ev[i] = torch.cuda.Event()
+            self._kp_ev[i].record()
+        return t[:kp.size].view(kp.shape), t[kp.size:].view(vis.shape)
+
+    def _build(self, samples):
         d = self.cfg.data
-        for samples in self.loader:
-            img32, img16 = self.cropper([s["img"] for s in samples], [s["matrix"] for s in samples], [s.get("flip", False) for s in samples])
-            kp = torch.from_numpy(np.stack([s["keypoints"] for s in samples]).astype(np.float32)).to(self.device)
-            vis = torch.from_numpy(np.stack([s["keypoints_visible"] for s in samples]).astype(np.float32)).to(self.device)
-            target, weight = generate_target(kp, vis, d.input_size, d.heatmap_size, d.sigma)
-            f32 = lambda k: torch.from_numpy(np.stack([np.asarray(s[k], np.float32) for s in samples]))
-            yield {"img": img32, "img_nhwc8": img16, "target": target, "target_weight": weight, "keypoints": kp, "keypoints_visible": vis,
-                   "meta": {"image_id": torch.tensor([int(s["image_id"]) for s in samples]), "ann_id": torch.tensor([int(s["ann_id"]) for s in samples]),
-                            "center": f32("center"), "scale": f32("scale"), "bbox": f32("bbox"),
-                            "area": torch.tensor([float(s["area"]) for s in samples])}}
+        img32, img16 = self.cropper([s["img"] for s in samples], [s["matrix"] for s in samples], [s.get("flip", False) for s in samples])
+        kp, vis = self._keypoints_to_device(samples)
+        target, weight = generate_target(kp, vis, d.input_size, d.heatmap_size, d.sigma)
+        f32 = lambda k: torch.from_numpy(np.stack([np.asarray(s[k], np.float32) for s in samples]))
+        return {"img": img32, "img_nhwc8": img16, "target": target, "target_weight": weight, "keypoints": kp, "keypoints_visible": vis,
+                "meta": {"image_id": torch.tensor([int(s["image_id"]) for s in samples]), "ann_id": torch.tensor([int(s["ann_id"]) for s in samples]),
+                         "center": f32("center"), "scale": f32("scale"), "bbox": f32("bbox"),
+                         "area": torch.tensor([float(s["area"]) for s in samples])}}
+
+    def _prepare(self, samples):
+        """Enqueue the device work of one batch on the side stream -> (batch, event that marks it ready)."""
+        with torch.cuda.stream(self._stream):
+            batch = self._build(samples)
+            ev = torch.cuda.Event()
+            ev.record()
+        return batch, ev
+
+    def _hand_out(self, pending):
+        batch, ev = pending
+        cur = torch.cuda.current_stream()
+        cur.wait_event(ev)
+        for v in batch.values():
+            if torch.is_tensor(v) and v.is_cuda:
+                v.record_stream(cur)
+        return batch
+
+    def __iter__(self):
+        if not self.prefetch:
+            for samples in self.loader:
+                yield self._build(samples)
+            return
+        it = iter(self.loader)
+        samples = next(it, None)
+        pending = self._prepare(samples) if samples is not None else None
+        while pending is not None:
+            batch = self._hand_out(pending)
+            samples = next(it, None)                   # batch n + 1 goes to the side stream before batch n is handed out: its copy and
+            pending = self._prepare(samples) if samples is not None else None      # kernels run beside the consumer's step n
+            yield batch
 
 
 def build_coco_dataloader(cfg, is_train: bool = True, device="cuda"):

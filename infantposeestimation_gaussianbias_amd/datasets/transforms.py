@@ -186,6 +186,19 @@ class DeviceCropper:
 
     def __init__(self, input_size, device="cuda", nchw=True, nhwc8=True):
         self.w, self.h, self.device, self.nchw, self.nhwc8 = int(input_size[0]), int(input_size[1]), torch.device(device), nchw, nhwc8
+        # two reusable pinned staging buffers (pin_memory() per batch is a hipHostMalloc of ~15 MB each time); a slot is rewritten only
+        # after the host-to-device copy that last read it has completed (its event)
+        self._pinned, self._pin_ev, self._slot = [None, None], [None, None], 0
+
+    def _staging(self, nbytes):
+        if not torch.cuda.is_available():
+            return torch.empty(nbytes, dtype=torch.uint8), None
+        i = self._slot = self._slot ^ 1
+        if self._pin_ev[i] is not None:
+            self._pin_ev[i].synchronize()
+        if self._pinned[i] is None or self._pinned[i].numel() < nbytes:
+            self._pinned[i] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8).pin_memory()
+        return self._pinned[i][:nbytes], i
 
     def __call__(self, images, matrices, flips=None, bgr=False):
         B = len(images)
@@ -200,15 +213,19 @@ class DeviceCropper:
             desc[i] = (off, im.shape[0], im.shape[1], int(bool(flips[i])) if flips is not None else 0, int(bool(bgr)), invert_affine(matrices[i]))
             sizes.append(im)
             off += (im.size + 15) // 16 * 16
-        host = torch.empty(off, dtype=torch.uint8).pin_memory() if torch.cuda.is_available() else torch.empty(off, dtype=torch.uint8)
+        nd = desc.nbytes
+        host, slot = self._staging(off + (nd + 15) // 16 * 16)          # [images | descriptor table]: ONE host-to-device copy
         for i, im in enumerate(sizes):
             o = int(desc[i]["off"])
             host[o:o + im.size] = torch.from_numpy(np.ascontiguousarray(im).reshape(-1))
-        src = host.to(self.device, non_blocking=True)
-        dtab = torch.from_numpy(desc.view(np.uint8)).to(self.device, non_blocking=True)
+        host[off:off + nd] = torch.from_numpy(desc.view(np.uint8))
+        dev_buf = host.to(self.device, non_blocking=True)
+        if slot is not None:
+            self._pin_ev[slot] = torch.cuda.Event()
+            self._pin_ev[slot].record()
+        src, dtab = dev_buf[:off], dev_buf[off:off + nd]
         out32 = torch.empty(B, 3, self.h, self.w, dtype=torch.float32, device=self.device) if self.nchw else None
         out16 = torch.empty(B, self.h, self.w, 8, dtype=torch.bfloat16, device=self.device) if self.nhwc8 else None
         call("pk_affine_crop_normalize", src, dtab, B, self.w, self.h, out32, out16, MEAN.ctypes.data, STD.ctypes.data, stream_ptr())
-        for t in (src, dtab):
-            t.record_stream(torch.cuda.current_stream())
+        dev_buf.record_stream(torch.cuda.current_stream())
         return out32, out16

@@ -1106,8 +1106,17 @@ def exchange(xs, fuse, training, n_out=None, first_only=False):
     afterwards -- 18.9 -> 19.2 .. 19.5 ms: every x_j then also gets a gradient from outside the region, i.e. four extra elementwise
     adds per unit on the main stream.  The unit stays a chain of launch-latency-bound kernels on small tensors: ~0.3 ms backward per unit with ~0.3
     kernels in flight, profiles/r02_trace_summary.txt.)"""
-    from . import dispatch
+    from . import dispatch, exchange as xg
     n = len(xs)
+    if xg.usable(training) and 1 < n <= 4 and (first_only or xg.whole_unit()):
+        # grouped launches: one launch per kernel family and dependency level of the unit (exchange.py)
+        if first_only:
+            y0 = xg.unit(xs, fuse, training, outs=[0])
+            if training:        # the unused outputs (see below): BatchNorm running statistics only, off the critical path
+                det = [t.detach() for t in xs]
+                dispatch.run_detached(lambda: xg.unit(det, fuse, training, outs=range(1, n)), det)
+            return y0
+        return xg.unit(xs, fuse, training, outs=range(n if n_out is None else n_out))
     if first_only and n > 1 and os.environ.get("POSE_LAST_EXCHANGE_DETACHED", "1") != "0":
         # Last module of the network: only output 0 is consumed (hrformer.py:776 / hrnet.py:441).  The reference still computes outputs
         # 1..n-1; their only lasting effect is the running-statistics update of their BatchNorm layers in training mode.  They leave the
@@ -1125,6 +1134,10 @@ def exchange(xs, fuse, training, n_out=None, first_only=False):
 def exchange_output(i, xs, fuse, training):
     """Output i of an exchange unit: relu(sum_j route_{j->i}(x_j)).  Also called from inside the NEXT module's branch task i
     (models: chained modules), so that branch i starts as soon as ITS input is ready instead of after the slowest output."""
+    from . import exchange as xg
+    if xg.usable(training) and 1 < len(xs) <= 4:
+        # the routes into output i as grouped launches: one launch per kernel family and chain level (exchange.py)
+        return xg.unit(list(xs), fuse, training, outs=[i])[0]
     terms = []
     for j in range(len(xs)):
         if j == i:

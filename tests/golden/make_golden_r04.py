@@ -43,10 +43,10 @@ def cap_constraint(out, tag, B, K, H, W, win, hin):
     sig.backward(gs)
     out[f"{tag}.sigma"], out[f"{tag}.sigma_g"], out[f"{tag}.sigma_dhm"], out[f"{tag}.sigma_dc"] = N(sig), N(gs), N(h.grad), N(c.grad)
     # the three terms one by one (+ the variance term without the prediction branch), then forward() with mixed upstream weights
-    for name, fn in (("var_nopred", lambda h, c, v: gc.variance_alignment_loss(h, c, T(w), None)),
-                     ("var", lambda h, c, v: gc.variance_alignment_loss(h, c, T(w), v)),
-                     ("ovl", lambda h, c, v: gc.spatial_overlap_loss(h, T(w))),
-                     ("shape", lambda h, c, v: gc.distribution_shape_loss(h, T(w)))):
+    for name, fn in (("t_var_nopred", lambda h, c, v: gc.variance_alignment_loss(h, c, T(w), None)),
+                     ("t_var", lambda h, c, v: gc.variance_alignment_loss(h, c, T(w), v)),
+                     ("t_ovl", lambda h, c, v: gc.spatial_overlap_loss(h, T(w))),
+                     ("t_shape", lambda h, c, v: gc.distribution_shape_loss(h, T(w)))):
         h, c, v = leaf(hm), leaf(coords), leaf(var)
         val = fn(h, c, v)
         val.backward()

@@ -1069,3 +1069,91 @@ def test_softargmax_beta_and_overlap_threshold_vs_oracle(golden):
 
 def G(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to(DEV, dtype)
+
+
+# ------------------------------------------------------------------------------------------------ grouped exchange unit (round 4)
+@pytest.mark.parametrize("sinks", [False, True])
+@pytest.mark.parametrize("grouped", ["1", "2"])
+@pytest.mark.parametrize("channels,sizes,first_only", [((32, 64, 128, 256), ((16, 12), (8, 6), (4, 3), (2, 2)), False),
+                                                       ((32, 64, 128), ((18, 14), (9, 7), (5, 4)), False),
+                                                       ((16, 32), ((12, 10), (6, 5)), False),
+                                                       ((32, 64, 128, 256), ((16, 12), (8, 6), (4, 3), (2, 2)), True)])
+def test_grouped_exchange_unit_is_identical_to_the_per_layer_path(N, monkeypatch, channels, sizes, first_only, sinks, grouped):
+    """exchange.py (one launch per kernel family and dependency level of the unit) against the per-layer launches of round 3: the SAME
+    kernel bodies on the same operands, so outputs, BatchNorm gradients and running statistics must agree bit for bit; weight gradients
+    come from a different slice split of the pixel rows (fixed tile shape per member kind) and are held to 1e-5 of fp32; an input's gradient
+    is ONE fp32 sum of its routes' data gradients rounded once (per-layer path: successive bf16 additions) -> bf16 rounding apart.
+    `grouped`: 1 = one grouped task per output (the chained modules' form), 2 = the whole unit at once.
+    `sinks`: parameter gradients stored through gradient sinks with the slab reduction postponed (the engine's path) or plain autograd."""
+    import copy
+    from infantposeestimation_gaussianbias_amd import dispatch, nnops
+    from infantposeestimation_gaussianbias_amd.models._blocks import make_fuse_layers
+    torch.manual_seed(5)
+    fuse0 = make_fuse_layers(list(channels))
+    with torch.no_grad():
+        for m in fuse0.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+                m.bias.copy_(torch.randn_like(m.bias) * 0.2)
+    B = 3
+    xs = [rnd(B, c, h, w, seed=10 + i) for i, (c, (h, w)) in enumerate(zip(channels, sizes))]
+    res = {}
+    for mode in ("0", grouped):
+        monkeypatch.setenv("POSE_GROUPED_EXCHANGE", mode)
+        holder = Holder(f=copy.deepcopy(fuse0)).to(DEV).train()
+        params = dict(holder.f.named_parameters())
+        if sinks:
+            nnops.begin_grad_epoch()
+            for p in params.values():
+                p._pk_grad_sink = torch.full_like(p, float("nan"))
+        xd = [nhwc(t).requires_grad_(True) for t in xs]
+        with dispatch.scope(holder):
+            ys = dispatch.exchange(xd, holder.f, True, first_only=first_only)
+            gys = [nhwc(rnd(*nchw(y).shape, seed=40 + i)) for i, y in enumerate(ys)]
+            sum((y.float() * g.float()).sum() for y, g in zip(ys, gys)).backward()
+            nnops.finalize_deferred()
+        torch.cuda.synchronize()
+        grads = {k: (p._pk_grad_sink if sinks else p.grad) for k, p in params.items()}
+        if first_only:      # parameters of the unused outputs get no gradient on either path
+            grads = {k: g for k, g in grads.items() if g is not None and not torch.isnan(g).any()}
+        res[mode] = dict(ys=[C(y) for y in ys], gx=[C(t.grad) for t in xd], g={k: C(g) for k, g in grads.items()},
+                         buf={k: C(v) for k, v in holder.f.state_dict().items() if "running" in k or "num_batches" in k})
+    a, b = res["0"], res[grouped]
+    assert len(a["ys"]) == len(b["ys"]) == (1 if first_only else len(channels))
+    for i, (u, v) in enumerate(zip(a["ys"], b["ys"])):
+        assert torch.equal(u, v), f"output {i}"
+    for i, (u, v) in enumerate(zip(a["gx"], b["gx"])):
+        assert err(v, u) < 1.6e-2 and err2(v, u) < 4e-3, f"input gradient {i}: {err(v, u)} {err2(v, u)}"
+    assert a["g"].keys() == b["g"].keys() and len(a["g"]) > 0
+    for k in a["g"]:
+        if k.endswith(".0.weight"):
+            assert err(b["g"][k], a["g"][k]) < 1e-5, (k, err(b["g"][k], a["g"][k]))
+        else:
+            assert torch.equal(a["g"][k], b["g"][k]), k
+    for k in a["buf"]:
+        assert torch.equal(a["buf"][k], b["buf"][k]), k
+
+
+def test_grouped_exchange_unit_eval_forward_matches_per_layer_path(N, monkeypatch):
+    """Inference (no autograd, running statistics): every level is ONE conv launch with the BatchNorm affine map in its epilogue."""
+    import copy
+    from infantposeestimation_gaussianbias_amd import dispatch
+    from infantposeestimation_gaussianbias_amd.models._blocks import make_fuse_layers
+    torch.manual_seed(6)
+    fuse0 = make_fuse_layers([32, 64, 128, 256])
+    with torch.no_grad():
+        for m in fuse0.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand_like(m.weight) + 0.5)
+                m.bias.copy_(torch.randn_like(m.bias) * 0.2)
+                m.running_mean.copy_(torch.randn_like(m.running_mean) * 0.1)
+                m.running_var.copy_(torch.rand_like(m.running_var) + 0.5)
+    xs = [rnd(2, c, h, w, seed=20 + i) for i, (c, (h, w)) in enumerate(zip((32, 64, 128, 256), ((24, 18), (12, 9), (6, 5), (3, 3))))]
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("POSE_GROUPED_EXCHANGE", mode)
+        holder = Holder(f=copy.deepcopy(fuse0)).to(DEV).eval()
+        with torch.no_grad(), dispatch.scope(holder):
+            outs[mode] = [C(y) for y in dispatch.exchange([nhwc(t) for t in xs], holder.f, False)]
+    for i, (u, v) in enumerate(zip(outs["0"], outs["1"])):
+        assert torch.equal(u, v), (i, err(v, u))

@@ -44,10 +44,10 @@ def test_gaussian_constraint_methods_vs_reference(golden, tag):
     assert close(C(sig), z[f"{tag}.sigma"])
     sig.backward(G(z[f"{tag}.sigma_g"]))
     assert close(C(h.grad), z[f"{tag}.sigma_dhm"]) and close(C(c.grad), z[f"{tag}.sigma_dc"])
-    for name, fn in (("var_nopred", lambda h, c, v: gc.variance_alignment_loss(h, c, w, None)),
-                     ("var", lambda h, c, v: gc.variance_alignment_loss(h, c, w, v)),
-                     ("ovl", lambda h, c, v: gc.spatial_overlap_loss(h, w)),
-                     ("shape", lambda h, c, v: gc.distribution_shape_loss(h, w))):
+    for name, fn in (("t_var_nopred", lambda h, c, v: gc.variance_alignment_loss(h, c, w, None)),
+                     ("t_var", lambda h, c, v: gc.variance_alignment_loss(h, c, w, v)),
+                     ("t_ovl", lambda h, c, v: gc.spatial_overlap_loss(h, w)),
+                     ("t_shape", lambda h, c, v: gc.distribution_shape_loss(h, w))):
         h, c, v = G(z[f"{tag}.hm"], True), G(z[f"{tag}.coords"], True), G(z[f"{tag}.var"], True)
         val = fn(h, c, v)
         assert val.dim() == 0 and close(C(val), z[f"{tag}.{name}"]), (name, float(val), float(z[f"{tag}.{name}"]))

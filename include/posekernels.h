@@ -8,7 +8,10 @@
  * Conventions (all entries):
  *   - extern "C", plain pointers and sizes; no C++/torch types.
  *   - every pointer is a BORROWED DEVICE pointer (caller allocates inputs, outputs and workspaces);
- *     the library allocates nothing and keeps no state besides a thread-local error string.
+ *     the library allocates nothing and keeps no state besides a thread-local error string.  It reads four environment
+ *     switches, per call, that route convolutions to / away from the two specialised kernels (PK_CONV8P, PK_CONV8P_MIN_TILES,
+ *     PK_CONV3H, PK_CONV3H_MIN_TILES: used by the parity tests to push small shapes through them); the tuning knobs of the
+ *     measurement rounds are compile-time constants unless the library is built with `make TUNING=1`.
  *   - asynchronous on `stream` (a hipStream_t passed as void*); no internal synchronisation; graph-capturable.
  *   - returns 0 on success, a negative PK_ERR_* on argument validation failure (nothing launched),
  *     or a positive hipError_t from the launch.  Never throws, never aborts.

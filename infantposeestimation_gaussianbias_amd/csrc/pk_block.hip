@@ -1612,7 +1612,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
 }
 
 static inline int attn_blocks(int n_windows) {
-    static const int cap = getenv("PK_ATTN_WGS") ? atoi(getenv("PK_ATTN_WGS")) : 1024;
+    static const int cap = PK_KNOB("PK_ATTN_WGS", 1024);
     const int need = (n_windows + 3) / 4;
     return need < cap ? (need < 1 ? 1 : need) : cap;
 }
@@ -1664,8 +1664,8 @@ extern "C" int pk_attn_block_fwd(const void* x, const int32_t* rowmap, const flo
 
 // Head_dim-40 twins, forward only.  `n_windows` > 0 also asks whether the launch has enough windows to pay (one wave per window).
 extern "C" int pk_attn_block_wide_supported(int C, int heads, int n_windows) {
-    static const int on = getenv("PK_ATTN_WIDE") ? atoi(getenv("PK_ATTN_WIDE")) : 1;
-    static const int min_win = getenv("PK_ATTN_WIDE_MIN_WINDOWS") ? atoi(getenv("PK_ATTN_WIDE_MIN_WINDOWS")) : 1024;
+    static const int on = PK_KNOB("PK_ATTN_WIDE", 1);
+    static const int min_win = PK_KNOB("PK_ATTN_WIDE_MIN_WINDOWS", 1024);
     if (!(on && C == 80 && heads == 2)) return 0;
     return n_windows <= 0 || n_windows >= min_win;
 }
@@ -1681,7 +1681,7 @@ static int attn_wide_launch(const AttnArgs& a, int C, int c_real, hipStream_t st
         }
         attr_set = true;
     }
-    static const int cap = getenv("PK_ATTN_WIDE_WGS") ? atoi(getenv("PK_ATTN_WIDE_WGS")) : 256;      // one 8-wave workgroup per CU (104 KB of LDS)
+    static const int cap = PK_KNOB("PK_ATTN_WIDE_WGS", 256);      // one 8-wave workgroup per CU (104 KB of LDS)
     const int need = (a.n_windows + WAVES - 1) / WAVES;
     hipLaunchKernelGGL((k_attn_fwd_w<NK, NCT, HEADS, WAVES>), dim3(need < cap ? need : cap), dim3(64 * WAVES), lds, st, a, C, c_real);
     return pk_launch_status("pk_attn_block_wide_fwd");
@@ -1706,7 +1706,7 @@ extern "C" int pk_attn_block_wide_fwd(const void* x, const int32_t* rowmap, cons
 
 // ================================================================================================ C-ABI
 static inline int mlp_hidden_slice(int C) {          // hidden units per blockIdx.y slice of the weight-gradient kernel
-    static const int env = getenv("PK_MLP_HS") ? atoi(getenv("PK_MLP_HS")) : 0;
+    static const int env = PK_KNOB("PK_MLP_HS", 0);
     if (env == 32 || env == 64 || (env == 128 && C == 32)) return env;
     // Measured (B = 64): the 128 accumulator registers of HS * C = 4096 hold the kernel at one wave per SIMD (C = 32: 66 us);
     // half of that (two waves per SIMD) runs the same work in 40 us although every slice recomputes LayerNorm.
@@ -1721,7 +1721,7 @@ extern "C" int pk_ln_mlp_slab_floats(int C) {
 }
 // workgroups (4 waves, one 32-token group per wave and iteration): enough to fill 256 CUs twice, never more than the work
 static inline int mlp_blocks(int M, int target) {
-    static const int env_target = getenv("PK_MLP_WGS") ? atoi(getenv("PK_MLP_WGS")) : 0;
+    static const int env_target = PK_KNOB("PK_MLP_WGS", 0);
     if (env_target > 0) target = env_target;
     const int need = (mlp_row_groups(M) + 3) / 4;
     return need < target ? (need < 1 ? 1 : need) : target;
@@ -1771,8 +1771,8 @@ static int pk_cu_count_block() {
 // (108 workgroups) 151 us against ~70 us for the unfused fc1 + fc2 GEMMs (step 29.35 ms with it, 27.45 ms without), while C = 80
 // (864 workgroups) and C = 160 (216) win 2.4 ms per step.  Default: at least PK_MLP_WIDE_MIN_WGS = 160 workgroups.
 extern "C" int pk_ln_mlp_wide_supported(int C, int hidden, int M) {
-    static const int on = getenv("PK_MLP_WIDE") ? atoi(getenv("PK_MLP_WIDE")) : 1;
-    static const int min_wgs = getenv("PK_MLP_WIDE_MIN_WGS") ? atoi(getenv("PK_MLP_WIDE_MIN_WGS")) : 160;
+    static const int on = PK_KNOB("PK_MLP_WIDE", 1);
+    static const int min_wgs = PK_KNOB("PK_MLP_WIDE_MIN_WGS", 160);
     if (!(on && (C == 80 || C == 128 || C == 160 || C == 256 || C == 320) && hidden > 0 && hidden % 32 == 0 && hidden <= 2048)) return 0;
     const int per_wg = C >= 256 ? 128 : 256;
     return M <= 0 || (M + per_wg - 1) / per_wg >= min_wgs;
@@ -1780,7 +1780,7 @@ extern "C" int pk_ln_mlp_wide_supported(int C, int hidden, int M) {
 template <int NK, int NCT, int WAVES>
 static int mlp_wide_launch(const MlpArgs& a, int C, int c_real, int HD, hipStream_t st) {
     constexpr int NF = 2 * NK + NCT;
-    static const int res_on = getenv("PK_MLP_WIDE_RESIDENT") ? atoi(getenv("PK_MLP_WIDE_RESIDENT")) : 1;
+    static const int res_on = PK_KNOB("PK_MLP_WIDE_RESIDENT", 1);
     const int NS = HD / 32, lds_res = NS * NF * 1024 + HD * 4;
     const bool resident = res_on && lds_res <= 150 * 1024;         // every slice fits: stage once, persistent workgroups, no per-slice barrier
     const int lds = resident ? lds_res : 2 * NF * 1024 + HD * 4;

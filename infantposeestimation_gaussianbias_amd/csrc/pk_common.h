@@ -6,6 +6,18 @@
 
 #include "../../include/posekernels.h"
 
+// Tuning knobs.  The RELEASE library reads nothing from the environment except the four documented routing switches of the two specialised
+// convolution kernels (PK_CONV8P, PK_CONV8P_MIN_TILES, PK_CONV3H, PK_CONV3H_MIN_TILES: the parity tests lower the thresholds to push small
+// and ragged shapes through them): every other knob of the measurement rounds is the compile-time constant it was left at.  A tuning build
+// (`make TUNING=1`, -DPK_TUNING) turns the knobs back into environment reads for A/B runs on one box.
+#ifdef PK_TUNING
+#include <stdlib.h>
+#define PK_KNOB(name, dflt) (getenv(name) ? atol(getenv(name)) : (long)(dflt))
+#else
+#define PK_KNOB(name, dflt) (dflt)
+#endif
+
+
 #define PK_WAVE 64
 
 void pk_set_error(const char* fmt, ...);

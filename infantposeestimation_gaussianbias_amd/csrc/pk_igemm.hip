@@ -1305,7 +1305,7 @@ static void igemm_log_dump() {
     for (auto& kv : igemm_log()) fprintf(stderr, "# igemm %6d x %s\n", kv.second, kv.first.c_str());
 }
 static void igemm_log_add(const IgemmArgs& a) {
-    static const bool on = getenv("PK_IGEMM_LOG") && atoi(getenv("PK_IGEMM_LOG"));
+    static const bool on = PK_KNOB("PK_IGEMM_LOG", 0) != 0;
     if (!on) return;
     static bool reg = false;
     if (!reg) {
@@ -1330,11 +1330,11 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     igemm_log_add(a);
     a.vec8 = (a.ldo % 8) == 0 &&
              ((((uintptr_t)a.out | (uintptr_t)a.res | (uintptr_t)a.preact | (uintptr_t)a.gelu_of) & 15) == 0);
-    static const int xcd_on = getenv("PK_IGEMM_XCD") ? atoi(getenv("PK_IGEMM_XCD")) : 1;
+    static const int xcd_on = PK_KNOB("PK_IGEMM_XCD", 1);
     a.xcd_remap = xcd_on;
-    static const int cm_on = getenv("PK_IGEMM_CHUNK_MAJOR") ? atoi(getenv("PK_IGEMM_CHUNK_MAJOR")) : 1;
+    static const int cm_on = PK_KNOB("PK_IGEMM_CHUNK_MAJOR", 1);
     a.chunk_major = cm_on && a.T == 9 && a.N <= 32 && a.Cin >= 128 && (a.Cin % 64) == 0 && !a.dilated;      // (the dilated walk has its own tap list)
-    static const int dg_on = getenv("PK_IGEMM_DILGROUP") ? atoi(getenv("PK_IGEMM_DILGROUP")) : 1;
+    static const int dg_on = PK_KNOB("PK_IGEMM_DILGROUP", 1);
     a.dil_group = dg_on && a.dilated && a.T == 9 && a.out_mode == 0 && !a.stats && !a.o_rowmap && !a.res_scale;
     if (conv3h_takes(a)) return conv3h_launch(a, st, who);
     if (conv8p_takes(a)) {
@@ -1342,12 +1342,12 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
         return pk_launch_status(who);
     }
     const dim3 block(256);
-    static const int plain_on = getenv("PK_IGEMM_PLAIN") ? atoi(getenv("PK_IGEMM_PLAIN")) : 1;
+    static const int plain_on = PK_KNOB("PK_IGEMM_PLAIN", 1);
     const bool plain = plain_on && !a.dilated;
     const unsigned gm = (unsigned)((a.M + 127) / 128);
     // Deep contractions with wide outputs (the 3x3 convs of the head: K = 2304, N = 128/256): 256 x 128 workgroup tile, 128 x 64
     // per wave -- a third less LDS traffic per MFMA than the 64 x 64 wave tile, which is what bounds those kernels.
-    static const int big_on = getenv("PK_IGEMM_BIG") ? atoi(getenv("PK_IGEMM_BIG")) : 1;
+    static const int big_on = PK_KNOB("PK_IGEMM_BIG", 1);
     // (needs >= 1024 workgroups: with 768 -- N = 128 at M = 196 608 -- the second round of workgroups is half empty and the
     // kernel is slower than the 128 x 128 tile.  Measured at N = 256: fwd 361 -> 334 us, dgrad 306 -> 285 us.)
     if (big_on && (a.N % 128) == 0 && a.T * a.Cin >= 576 && (a.Cin % 32) == 0 && (long)((a.M + 255) / 256) * (a.N / 128) >= 1024) {
@@ -1357,9 +1357,9 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     // deeper K-chunks when the channel count allows full 64-wide tiles -- except for contractions of <= 128 (one or two steps): the BK = 32
     // variants hold half the LDS and run 4-7 waves per SIMD instead of 3, which is what an output-bound launch needs (1x1 64 -> 256 @64x48
     // data gradient 48.5 -> 37 us)
-    static const int shallow32 = getenv("PK_IGEMM_SHALLOW32") ? atoi(getenv("PK_IGEMM_SHALLOW32")) : 128;
+    static const int shallow32 = PK_KNOB("PK_IGEMM_SHALLOW32", 128);
     const bool k64 = (a.Cin % 64) == 0 && !(a.T * a.Cin <= shallow32);
-    static const int lean_on = getenv("PK_IGEMM_LEAN") ? atoi(getenv("PK_IGEMM_LEAN")) : 1;
+    static const int lean_on = PK_KNOB("PK_IGEMM_LEAN", 1);
     const bool lean_any = lean_on && a.T == 1 && a.Ho == 0 && !a.stats && a.act <= 1 && a.out_mode == 0 && a.vec8 && k64 && (a.N % 8) == 0;
     const bool lean = lean_any && !a.preact && !a.gelu_of && a.act == 0, lean_g = lean_any && !lean;
     // Shallow contractions (K = T*Cin <= 256: the token-MLP / qkv GEMMs) are bound by their output traffic, not MFMA:
@@ -1368,7 +1368,7 @@ static int igemm_launch(const IgemmArgs& a_in, hipStream_t st, const char* who) 
     // Few pixel rows (low-resolution branches: 24 .. 96 row tiles): a 128-wide N tile leaves most of the 256 CUs idle, so take
     // the widest N tile that still gives >= 512 workgroups (they are latency-bound, not MFMA-bound, at that size).
     // (128 x 64 tiles for the large convs were measured too: head conv 421 us instead of 361 us.)
-    static const int smallm_on = getenv("PK_IGEMM_SMALLM") ? atoi(getenv("PK_IGEMM_SMALLM")) : 1;
+    static const int smallm_on = PK_KNOB("PK_IGEMM_SMALLM", 1);
     const bool small_m = smallm_on && a.N > 64 && (long)gm * ((a.N + 127) / 128) < 512;
     if (small_m && (long)gm * ((a.N + 63) / 64) < 512 && !a.stats) {
         if (lean) hipLaunchKernelGGL((k_igemm2<128, 32, 4, 1, 64, 1>), dim3(gm, (a.N + 31) / 32), block, 0, st, a);
@@ -1910,7 +1910,7 @@ __global__ void __launch_bounds__(512, 2) k_wgrad3(WgradArgs p) {
         }
 }
 static inline bool wgrad_wide(int N, int Cin, int T) {
-    static const int on = getenv("PK_WGRAD_WIDE") ? atoi(getenv("PK_WGRAD_WIDE")) : 1;
+    static const int on = PK_KNOB("PK_WGRAD_WIDE", 1);
     return on && T == 9 && (N % 256) == 0 && (Cin % 256) == 0;
 }
 
@@ -2489,7 +2489,7 @@ __global__ void __launch_bounds__(256, 2) k_wgrad4_3x3(WgradArgs p) {
 }
 // which weight gradients the streaming kernels take: flags bit 0 = a_rowmap, 1 = g_rowmap, 2 = g_scale
 static inline int wgrad4_kind(int N, int Cin, int ksize, int stride, int Hs, int Ws, int flags) {
-    static const int on = getenv("PK_WGRAD4") ? atoi(getenv("PK_WGRAD4")) : 15;     // bit 0: single tap, 1: nine-tap 3x3, 2: column-form 3x3, 3: window / scaled rows
+    static const int on = PK_KNOB("PK_WGRAD4", 15);     // bit 0: single tap, 1: nine-tap 3x3, 2: column-form 3x3, 3: window / scaled rows
     if (flags) {       // gathered / scaled rows: linear form; a row map needs the token grid it is the window partition of
         if (ksize != 1 || stride != 1 || ((flags & 3) && (Hs <= 0 || Ws <= 0))) return 0;
         return (on & 8) ? 4 : 0;
@@ -2621,14 +2621,14 @@ static inline void wgrad_tile2(int N, int Cin, int T, int& tn, int& tc) {
 }
 static int wgrad_slices_old(int M, int N, int Cin, int T) {
     // enough workgroups to fill 256 CUs several times over (>= 2048), but no slice shorter than 256 rows
-    static const int target = getenv("PK_WGRAD_WGS") ? atoi(getenv("PK_WGRAD_WGS")) : 2048;
+    static const int target = PK_KNOB("PK_WGRAD_WGS", 2048);
     // (shorter slices for the low-resolution branches were measured: 64-row slices cost +1.3 ms per step in slab traffic; longer ones
     // are slower as well -- 512 / 1 024 rows: +0.35 / +1.8 ms per step -- each k_wgrad2 workgroup is bound by its own load latency)
-    static const int min_rows = getenv("PK_WGRAD_ROWS") ? atoi(getenv("PK_WGRAD_ROWS")) : 256;
+    static const int min_rows = PK_KNOB("PK_WGRAD_ROWS", 256);
     if (wgrad_wide(N, Cin, T)) {
         // one 512-thread workgroup per CU (128 KB LDS ring): ~one round of equal-sized workgroups over the 256 CUs, in whole groups of
         // 8 slices (one slice per XCD and group)
-        static const int wide_target = getenv("PK_WGRAD_WIDE_WGS") ? atoi(getenv("PK_WGRAD_WIDE_WGS")) : 256;
+        static const int wide_target = PK_KNOB("PK_WGRAD_WIDE_WGS", 256);
         const int tiles3 = (N / 256) * (Cin / 256) * T;
         int s3 = wide_target / tiles3 / 8 * 8;
         if (s3 < 8) s3 = 8;
@@ -2656,14 +2656,14 @@ static int wgrad4_slices(int rows, int N, int Cin, int kind) {
     // two workgroups per CU (single tap) / one (3x3: nine accumulator sets), slices of >= 512 rows: against 256 the step is unchanged
     // (17.3 / 17.6 ms on two boxes either way) and the slabs of the low-resolution branches halve (k_reduce_many 653 -> 570 us isolated);
     // 1 024 rows starve the small launches of workgroups (step + 0.6 ms)
-    static const int t1 = getenv("PK_WGRAD4_WGS") ? atoi(getenv("PK_WGRAD4_WGS")) : 512;
-    static const int t9 = getenv("PK_WGRAD4_WGS9") ? atoi(getenv("PK_WGRAD4_WGS9")) : 256;
-    static const int min_rows = getenv("PK_WGRAD4_ROWS") ? atoi(getenv("PK_WGRAD4_ROWS")) : 512;
+    static const int t1 = PK_KNOB("PK_WGRAD4_WGS", 512);
+    static const int t9 = PK_KNOB("PK_WGRAD4_WGS9", 256);
+    static const int min_rows = PK_KNOB("PK_WGRAD4_ROWS", 512);
     int tn, tc;
     wgrad4_tile(N, Cin, kind, tn, tc);
     const int tiles = ((N + tn - 1) / tn) * (((kind == 3 ? 9 * Cin : Cin) + tc - 1) / tc);
     int s = ((kind == 2 ? t9 : t1) + tiles - 1) / tiles;
-    static const int min_rows_w = getenv("PK_WGRAD4W_ROWS") ? atoi(getenv("PK_WGRAD4W_ROWS")) : min_rows;      // kind 4: window-gathered / row-scaled
+    static const int min_rows_w = PK_KNOB("PK_WGRAD4W_ROWS", min_rows);      // kind 4: window-gathered / row-scaled
     const int mr = kind == 4 ? min_rows_w : min_rows;
     const int max_s = (rows + mr - 1) / mr;
     if (s > max_s) s = max_s;
@@ -2768,7 +2768,7 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
         a.m_per_slice = ((rows + S - 1) / S + 31) / 32 * 32;
         const dim3 grid(8 * ((S + 7) / 8) * a.ntiles3);
         if (kind4 == 4) {
-            static const int w4_modes = getenv("PK_WGRAD4W_MODES") ? atoi(getenv("PK_WGRAD4W_MODES")) : 1;
+            static const int w4_modes = PK_KNOB("PK_WGRAD4W_MODES", 1);
             const bool gw_ = a.g_rowmap != nullptr, xw_ = a.a_rowmap != nullptr, sc_ = a.g_scale != nullptr;
             const int mode = !w4_modes ? 0 : (xw_ && !gw_ && !sc_) ? 1 : (gw_ && sc_ && !xw_) ? 2 : (sc_ && !gw_ && !xw_) ? 3 : 0;
 #define W4W_GO(TN_, TC_)                                                                                     \
@@ -2805,7 +2805,7 @@ extern "C" int pk_wgrad_bf16(const void* x, const void* grad_out, float* workspa
         hipLaunchKernelGGL(k_wgrad3, dim3(8 * ((S + 7) / 8) * 9 * a.ntiles3), dim3(512), W3_LDS, st, a);
     } else {
         dim3 grid(((N + tn - 1) / tn) * a.ctiles, a.T, S);
-        static const int xcd9 = getenv("PK_WGRAD2_XCD") ? atoi(getenv("PK_WGRAD2_XCD")) : 1;
+        static const int xcd9 = PK_KNOB("PK_WGRAD2_XCD", 1);
         if (a.T == 9 && xcd9) {
             a.ntiles3 = grid.x;
             a.nslices3 = S;

@@ -308,7 +308,7 @@ extern "C" int pk_bn_train_fwd(const void* raw, const float* stats_partial, int 
                                int relu, void* stream) {
     PK_REQUIRE(raw && stats_partial && gamma && beta && y && save_mean && save_rstd && scale && shift, "pk_bn_train_fwd: null pointer");
     PK_REQUIRE(tiles > 0 && C > 0 && (C & 7) == 0 && rows > 0, "pk_bn_train_fwd: bad sizes");
-    static const int fused_on = getenv("PK_BN_FUSED") ? atoi(getenv("PK_BN_FUSED")) : 1;
+    static const int fused_on = PK_KNOB("PK_BN_FUSED", 1);
     if (fused_on && tiles <= BNS_MAX_TILES && rows <= 32768) {
         const int ncg = (C + BNS_CG - 1) / BNS_CG;
         int nrb = (int)((rows + 127) / 128);                       // >= 128 rows per workgroup, ~256 workgroups in all
@@ -422,8 +422,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ 
 // (PK_BN_FUSED_ROWS / PK_BN_FUSED_NB, measured on HRNet-W32 384x288 training, 22.23 ms per step at the defaults: 262 144 rows with 128 / 256
 // partial rows 23.57 / 23.06 ms, 65 536 rows with 128 partial rows 22.29 ms -- the large tensors keep the three-launch form)
 static inline bool bn_bwd_small(int64_t rows) {
-    static const int fused_on = getenv("PK_BN_FUSED") ? atoi(getenv("PK_BN_FUSED")) : 1;
-    static const long max_rows = getenv("PK_BN_FUSED_ROWS") ? atol(getenv("PK_BN_FUSED_ROWS")) : 32768;
+    static const int fused_on = PK_KNOB("PK_BN_FUSED", 1);
+    static const long max_rows = PK_KNOB("PK_BN_FUSED_ROWS", 32768);
     return fused_on && rows <= max_rows;
 }
 extern "C" int pk_bn_bwd_blocks(int64_t rows) {
@@ -431,7 +431,7 @@ extern "C" int pk_bn_bwd_blocks(int64_t rows) {
     // workgroups (rows/256 left them with 12 .. 48 and a 55 us kernel for 3 MB of data).  Small tensors: at most 64 blocks, because
     // every workgroup of the fused apply kernel re-reduces the partial sums of its 32 channels itself (64 x 2 x 32 floats = 16 KB).
     int64_t nb = (rows + 31) / 32;
-    static const int small_nb = getenv("PK_BN_FUSED_NB") ? atoi(getenv("PK_BN_FUSED_NB")) : 64;
+    static const int small_nb = PK_KNOB("PK_BN_FUSED_NB", 64);
     if (bn_bwd_small(rows) && nb > small_nb) nb = small_nb;
     return (int)(nb > 1024 ? 1024 : (nb < 1 ? 1 : nb));
 }

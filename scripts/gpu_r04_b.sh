@@ -15,6 +15,6 @@ for v in g1 g0 g2 g1b g0b; do
     g0|g0b) env_="POSE_GROUPED_EXCHANGE=0";;
   esac
   env $env_ timeout -k 10 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-roofline > gpurun_out/r04b_bench_$v.json 2> gpurun_out/r04b_bench_$v.err || { tail -8 gpurun_out/r04b_bench_$v.err | cut -c1-400; exit 1; }
-  echo "$v: $(python -c "import json,sys; d=json.loads(open('gpurun_out/r04b_bench_$v.json').read().strip().splitlines()[-1]); print(d["ms_per_step"], d["value"])")"
+  python scripts/bench_ms.py gpurun_out/r04b_bench_$v.json
 done
 exit $rc

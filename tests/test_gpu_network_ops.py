@@ -1080,8 +1080,8 @@ def G(a, dtype=torch.float32):
                                                        ((32, 64, 128, 256), ((16, 12), (8, 6), (4, 3), (2, 2)), True)])
 def test_grouped_exchange_unit_is_identical_to_the_per_layer_path(N, monkeypatch, channels, sizes, first_only, sinks, grouped):
     """exchange.py (one launch per kernel family and dependency level of the unit) against the per-layer launches of round 3: the SAME
-    kernel bodies on the same operands, so outputs, BatchNorm gradients and running statistics must agree bit for bit; weight gradients
-    come from a different slice split of the pixel rows (fixed tile shape per member kind) and are held to 1e-5 of fp32; an input's gradient
+    kernel bodies on the same operands, so the outputs must agree bit for bit; parameter gradients and running statistics are fp32 sums
+    taken in another order (tile shape of the statistics epilogue, slice split of the weight-gradient rows): 1e-5 / 1e-6; an input's gradient
     is ONE fp32 sum of its routes' data gradients rounded once (per-layer path: successive bf16 additions) -> bf16 rounding apart.
     `grouped`: 1 = one grouped task per output (the chained modules' form), 2 = the whole unit at once.
     `sinks`: parameter gradients stored through gradient sinks with the slab reduction postponed (the engine's path) or plain autograd."""
@@ -1125,13 +1125,13 @@ def test_grouped_exchange_unit_is_identical_to_the_per_layer_path(N, monkeypatch
     for i, (u, v) in enumerate(zip(a["gx"], b["gx"])):
         assert err(v, u) < 1.6e-2 and err2(v, u) < 4e-3, f"input gradient {i}: {err(v, u)} {err2(v, u)}"
     assert a["g"].keys() == b["g"].keys() and len(a["g"]) > 0
+    # (fp32 side results: the grouped convs all run on the 128 x 32 tile, the per-layer launcher picks 128 x 64 / 128 x 128 tiles for wide
+    # outputs, whose statistics epilogue sums a tile's rows in another wave order -- batch mean / variance agree to the last ulp or two,
+    # and so do the BatchNorm gradients and running statistics derived from them)
     for k in a["g"]:
-        if k.endswith(".0.weight"):
-            assert err(b["g"][k], a["g"][k]) < 1e-5, (k, err(b["g"][k], a["g"][k]))
-        else:
-            assert torch.equal(a["g"][k], b["g"][k]), k
+        assert err(b["g"][k], a["g"][k]) < 1e-5, (k, err(b["g"][k], a["g"][k]))
     for k in a["buf"]:
-        assert torch.equal(a["buf"][k], b["buf"][k]), k
+        assert err(b["buf"][k], a["buf"][k]) < 1e-6, k
 
 
 def test_grouped_exchange_unit_eval_forward_matches_per_layer_path(N, monkeypatch):

@@ -125,7 +125,8 @@ int pk_fusion_terms_fwd(const float* heatmaps, const float* offsets, const float
                         int B, int K, int H, int W, float in_w, float in_h, float sigma_t,
                         const float* lambdas7, int use_target_weight, void* stream);
 int pk_fusion_terms_bwd(const float* heatmaps, const float* target, const float* ws, const float* grad_total,
-                        const float* grad_sigma, float* d_heatmaps, float* d_offsets, float* d_variances, float* d_coords,
+                        const float* grad_sigma, const float* grad_losses /* 7 upstream gradients of `losses` or NULL (= total only) */,
+                        float* d_heatmaps, float* d_offsets, float* d_variances, float* d_coords,
                         int B, int K, int H, int W, float sigma_t, const float* lambdas7, void* stream);
 /* LocalGaussianRefinement.forward (models/fusion_head.py:74-128) about given coordinates; backward of SoftArgmax2D.forward (:24-71)        */
 int pk_local_gaussian_refine(const float* heatmaps, const float* coords_in, float* coords_out, int BK, int H, int W,

@@ -211,9 +211,12 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
                                                    const float* __restrict__ ws, const float* __restrict__ gtot,
                                                    float* __restrict__ dhm, float* __restrict__ doff, float* __restrict__ dvar,
                                                    int B, int K, int H, int W, float sigma_t, const float* __restrict__ lam,
-                                                   float* __restrict__ dcoords, const float* __restrict__ gsig) {
+                                                   float* __restrict__ dcoords, const float* __restrict__ gsig,
+                                                   const float* __restrict__ gvec) {
     // dcoords != NULL: the coordinates were handed in (k_floss_map's ext_c): their gradient goes to dcoords instead of through the
     // soft-argmax into the heatmap.  gsig (B*K) or NULL: upstream gradient on the per-map sigma (compute_heatmap_variance).
+    // gvec (7 floats) or NULL: upstream gradients of the seven returned values; term q is scaled by gvec[q] + gvec[6] (entry 6 is the sum)
+#define LG(q) (lam[q] * (gvec ? gvec[q] + gvec[6] : 1.f))
     const int map = blockIdx.x, b = map / K, k = map - b * K, n = H * W;
     const float* s = ws + (size_t)map * PK_LOSS_STAT;
     const float* pairs = ws + (size_t)B * K * PK_LOSS_STAT;
@@ -225,11 +228,11 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
     // d total / d c
     const float ex = s[ST_OX] - (s[ST_GX] - cx), ey = s[ST_OY] - (s[ST_GY] - cy);
     const float sgx = fabsf(ex) < 1.f ? ex : (ex > 0.f ? 1.f : -1.f), sgy = fabsf(ey) < 1.f ? ey : (ey > 0.f ? 1.f : -1.f);
-    const float koff = lam[1] * w3S * 0.5f;
-    const float kvar = (lam[3] * wS * 2.f * (s[ST_SIG] - sigma_t) + (gsig ? gsig[map] : 0.f)) / (2.f * s[ST_SIG]);   // d total / d spread
-    float gcx = lam[2] * w3S * 2.f * (cx - s[ST_GX]) + koff * (sgx * (s[ST_DOXX] + 1.f) + sgy * s[ST_DOYX]) +
+    const float koff = LG(1) * w3S * 0.5f;
+    const float kvar = (LG(3) * wS * 2.f * (s[ST_SIG] - sigma_t) + (gsig ? gsig[map] : 0.f)) / (2.f * s[ST_SIG]);   // d total / d spread
+    float gcx = LG(2) * w3S * 2.f * (cx - s[ST_GX]) + koff * (sgx * (s[ST_DOXX] + 1.f) + sgy * s[ST_DOYX]) +
                 kvar * (-2.f) * (s[ST_QX] - cx * s[ST_QSUM]);
-    float gcy = lam[2] * w3S * 2.f * (cy - s[ST_GY]) + koff * (sgx * s[ST_DOXY] + sgy * (s[ST_DOYY] + 1.f)) +
+    float gcy = LG(2) * w3S * 2.f * (cy - s[ST_GY]) + koff * (sgx * s[ST_DOXY] + sgy * (s[ST_DOYY] + 1.f)) +
                 kvar * (-2.f) * (s[ST_QY] - cy * s[ST_QSUM]);
     if (dcoords) {
         if (threadIdx.x == 0) {
@@ -238,8 +241,8 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
         }
         gcx = gcy = 0.f;
     }
-    const float khm = lam[0] * w3S * 2.f / (float)n;
-    const float ksh = lam[5] * wS * 2.f * (s[ST_ENT] - tent);
+    const float khm = LG(0) * w3S * 2.f / (float)n;
+    const float ksh = LG(5) * wS * 2.f * (s[ST_ENT] - tent);
     const float ubar = s[ST_UBAR], spread = s[ST_SPREAD], rinv = 1.f / (s[ST_R] + EPS8);
     // overlap partners of this joint
     int other[4];
@@ -251,7 +254,7 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
         const int o = (i == k) ? j : i;
         const float* pr = pairs + ((size_t)b * 16 + p) * 4;
         const float O = pr[0], mn = pr[1], r = pr[2], v = pr[3];
-        const float kp = (r > lam[6]) ? G * lam[4] * v / den : 0.f;
+        const float kp = (r > lam[6]) ? G * LG(4) * v / den : 0.f;
         const float sk = s[ST_SSUM], so = ws[((size_t)b * K + o) * PK_LOSS_STAT + ST_SSUM];
         const float ind = sk < so ? 1.f : (sk == so ? 0.5f : 0.f);
         other[np] = o;
@@ -268,7 +271,7 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
     const float fx = x - (float)x0, fy = y - (float)y0;
     float* dox = doff + (size_t)map * 2 * n;
     float* doy = dox + n;
-    const float dvu = G * lam[3] * w / S * 2.f * (s[ST_MEANVAR] - sigma_t) / (float)n;
+    const float dvu = G * LG(3) * w / S * 2.f * (s[ST_MEANVAR] - sigma_t) / (float)n;
     float* dv = dvar + (size_t)map * n;
     for (int i = threadIdx.x; i < n; i += blockDim.x) {
         const int py = i / W, px = i - py * W;
@@ -295,14 +298,16 @@ __global__ void __launch_bounds__(256) k_floss_bwd(const float* __restrict__ hm,
         dv[i] = dvu;
     }
 }
+#undef LG
 
 extern "C" int pk_fusion_terms_bwd(const float* heatmaps, const float* target, const float* ws, const float* grad_total,
-                                   const float* grad_sigma, float* d_heatmaps, float* d_offsets, float* d_variances, float* d_coords,
-                                   int B, int K, int H, int W, float sigma_t, const float* lambdas6, void* stream) {
+                                   const float* grad_sigma, const float* grad_losses, float* d_heatmaps, float* d_offsets,
+                                   float* d_variances, float* d_coords, int B, int K, int H, int W, float sigma_t, const float* lambdas6,
+                                   void* stream) {
     PK_REQUIRE(heatmaps && target && ws && d_heatmaps && d_offsets && d_variances && lambdas6, "pk_fusion_terms_bwd: null pointer");
     PK_REQUIRE(B > 0 && K > 0 && H > 1 && W > 1, "pk_fusion_terms_bwd: bad shape");
     hipLaunchKernelGGL(k_floss_bwd, dim3(B * K), dim3(256), 0, (hipStream_t)stream, heatmaps, target, ws, grad_total, d_heatmaps,
-                       d_offsets, d_variances, B, K, H, W, sigma_t, lambdas6, d_coords, grad_sigma);
+                       d_offsets, d_variances, B, K, H, W, sigma_t, lambdas6, d_coords, grad_sigma, grad_losses);
     return pk_launch_status("pk_fusion_terms_bwd");
 }
 
@@ -311,8 +316,8 @@ extern "C" int pk_fusion_loss_bwd(const float* heatmaps, const float* offsets, c
                                   float* d_offsets, float* d_variances, int B, int K, int H, int W, float sigma_t,
                                   const float* lambdas6, void* stream) {
     (void)offsets; (void)variances; (void)weight;
-    return pk_fusion_terms_bwd(heatmaps, target, ws, grad_total, nullptr, d_heatmaps, d_offsets, d_variances, nullptr, B, K, H, W, sigma_t,
-                               lambdas6, stream);
+    return pk_fusion_terms_bwd(heatmaps, target, ws, grad_total, nullptr, nullptr, d_heatmaps, d_offsets, d_variances, nullptr, B, K, H, W,
+                               sigma_t, lambdas6, stream);
 }
 
 // ================================================================================================ L3 / L4 pixel losses

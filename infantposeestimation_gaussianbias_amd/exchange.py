@@ -286,6 +286,19 @@ def unit(xs, fuse, training, outs=None):
     return list(_Unit.apply(plan, training, *xs, *plan.params()))
 
 
-def usable(training) -> bool:
-    """Grouped path: training mode, or no autograd at all (eval mode WITH autograd keeps the per-layer path)."""
-    return enabled() and (training or not torch.is_grad_enabled())
+MAX_ROWS = 65536
+
+
+def usable(training, xs=None) -> bool:
+    """Grouped path: training mode, or no autograd at all (eval mode WITH autograd keeps the per-layer path) -- and only while the unit is
+    launch-bound: every member runs on the 128 x 32 tile, which loses to the per-layer launcher's wide tiles / halo kernel once the
+    second-highest resolution has more than MAX_ROWS pixel rows.  Measured on one box: BASELINE cfg 2 (49 152 rows) 16.07 vs 16.37 ms,
+    cfg 4 (55 296 rows) 20.56 vs 21.19 ms per training step in favour of the groups; cfg 5 inference (110 592 rows) 17.78 vs 16.65 ms
+    against them."""
+    if not (enabled() and (training or not torch.is_grad_enabled())):
+        return False
+    if xs is not None and len(xs) > 1:
+        t = xs[1]
+        if t.shape[0] * t.shape[1] * t.shape[2] > MAX_ROWS:
+            return False
+    return True

@@ -166,9 +166,10 @@ class _FusionLoss(torch.autograd.Function):
         B, K, H, W = hm.shape
         # d(sum_i g_i * loss_i): entries 0..5 are the weighted terms and entry 6 their sum, so the per-term
         # multipliers are lambdas*(g[:6]+g[6]); the kernel takes them as "lambdas" with grad_total = 1.
-        eff = torch.cat([lambdas[:6] * (g[:6] + g[6]), lambdas[6:7]]).contiguous()
+        # (the kernel applies them: five tiny ATen launches at the very start of backward otherwise)
         dhm, doff, dvar = torch.empty_like(hm), torch.empty_like(off), torch.empty_like(var)
-        call("pk_fusion_loss_bwd", hm, off, var, target, weight, ws, None, dhm, doff, dvar, B, K, H, W, ctx.sigma_t, eff, stream_ptr())
+        call("pk_fusion_terms_bwd", hm, target, ws, None, None, _chk(g.float()), dhm, doff, dvar, None, B, K, H, W, ctx.sigma_t, lambdas,
+             stream_ptr())
         return dhm, doff, dvar, None, None, None, None, None, None, None, None
 
 
@@ -205,12 +206,11 @@ class _FusionTerms(torch.autograd.Function):
         hm, target, ws, lambdas = ctx.saved_tensors
         sigma_t, ext, off_shape = ctx.meta
         B, K, H, W = hm.shape
-        eff = torch.cat([lambdas[:6] * (g[:6] + g[6]), lambdas[6:7]]).contiguous()
         dhm, dvar = torch.empty_like(hm), torch.empty_like(hm)
         doff = torch.empty(off_shape, dtype=F32, device=hm.device)
         dco = torch.empty(B, K, 2, dtype=F32, device=hm.device) if ext else None
-        call("pk_fusion_terms_bwd", hm, target, ws, None, None if gsig is None else _chk(gsig.float()), dhm, doff, dvar, dco, B, K, H, W,
-             sigma_t, eff, stream_ptr())
+        call("pk_fusion_terms_bwd", hm, target, ws, None, None if gsig is None else _chk(gsig.float()), _chk(g.float()), dhm, doff, dvar, dco,
+             B, K, H, W, sigma_t, lambdas, stream_ptr())
         return dhm, doff, dvar, dco, None, None, None, None, None, None, None, None
 
 

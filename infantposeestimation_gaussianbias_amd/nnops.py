@@ -545,9 +545,19 @@ class _HeadOut(torch.autograd.Function):
         dx = _e((B, H, W, Cin), BF16, x.device)
         call("pk_conv2d_nhwc", g, wd, dx, None, None, B, H, W, Np, Cin, 1, 1, 0, H, W, 0, 0, None, stream_ptr())
         w_p, b_p = ctx.params
+        dst_w, dst_b = grad_sink_of(w_p), grad_sink_of(b_p)
+        if dst_w is not None and dst_b is not None and deferral_enabled():
+            # slabs only; the step's one pk_reduce_many sums the first N of the Np (8-aligned) rows straight into the sinks (was: a reduce
+            # launch + two copies per head output, at the very start of backward)
+            M = B * H * W
+            S = _lib.lib.pk_wgrad_slices(M, Np, Cin, 1, 1, H, W, 0)
+            ws = _workspace(dst_w, "w", S * Np * (Cin + 1))
+            call("pk_wgrad_bf16", x, g, ws, None, None, N, None, None, None, 0, M, Np, Cin, 1, 1, B, H, W, H, W, 1, stream_ptr())
+            _defer(ws.data_ptr(), dst_w, Np * Cin, S, N * Cin)
+            _defer(ws.data_ptr() + 4 * S * Np * Cin, dst_b, Np, S, N)
+            return dx, None, None, None
         db = _e((N,), F32, x.device)
         dw = _wgrad(x, g, Np, Cin, 1, 1, (B, H, W, H, W), dbias=db)[:N]
-        dst_w, dst_b = grad_sink_of(w_p), grad_sink_of(b_p)
         if dst_w is not None and dst_b is not None:
             dst_w.copy_(dw)
             dst_b.copy_(db)
@@ -1108,7 +1118,7 @@ def exchange(xs, fuse, training, n_out=None, first_only=False):
     kernels in flight, profiles/r02_trace_summary.txt.)"""
     from . import dispatch, exchange as xg
     n = len(xs)
-    if xg.usable(training) and 1 < n <= 4 and (first_only or xg.whole_unit()):
+    if xg.usable(training, xs) and 1 < n <= 4 and (first_only or xg.whole_unit()):
         # grouped launches: one launch per kernel family and dependency level of the unit (exchange.py)
         if first_only:
             y0 = xg.unit(xs, fuse, training, outs=[0])
@@ -1135,7 +1145,7 @@ def exchange_output(i, xs, fuse, training):
     """Output i of an exchange unit: relu(sum_j route_{j->i}(x_j)).  Also called from inside the NEXT module's branch task i
     (models: chained modules), so that branch i starts as soon as ITS input is ready instead of after the slowest output."""
     from . import exchange as xg
-    if xg.usable(training) and 1 < len(xs) <= 4:
+    if xg.usable(training, xs) and 1 < len(xs) <= 4:
         # the routes into output i as grouped launches: one launch per kernel family and chain level (exchange.py)
         return xg.unit(list(xs), fuse, training, outs=[i])[0]
     terms = []

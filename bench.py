@@ -500,6 +500,8 @@ def main():
             log(f"warm-up step {i}: {time.perf_counter() - t_w:.3f} s")
     if world > 1:
         dist.barrier()
+        if trainer is not None:
+            trainer.comm.record_exposed = True       # events around the exchange on the compute stream: exposed communication per step
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -551,6 +553,12 @@ def main():
         if comm_check is not None:
             comm_check["collectives_captured_in_graph"] = bool(c["mode"] == "train" and getattr(trainer, "_graph_has_comm", False))
             comm_check["buckets_launched_from_backward_milestones"] = int(trainer.comm.launched_early) if c["mode"] == "train" else None
+            # time per step the compute stream is held by the exchange (bucket launches that did not overlap + the wait for all of them);
+            # None when the collectives are captured inside the graph (POSE_GRAPH_COMM=1): then nothing of them is on the host's path
+            ex = trainer.comm.exposed_ms() if c["mode"] == "train" else None
+            comm_check["exposed_comm_ms_per_step"] = None if ex is None else round(ex, 3)
+            comm_check["gradient_bytes_per_step"] = int(trainer.opt.numel * 4) if c["mode"] == "train" else None
+            comm_check["buckets"] = len(trainer.comm.buckets) if c["mode"] == "train" else None
             line["comm"] = comm_check
         print(json.dumps(line))
     if world > 1:

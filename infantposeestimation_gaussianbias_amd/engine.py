@@ -229,6 +229,10 @@ class GradientExchange:
         self._armed = False
         self.suspended = False          # True while a hipGraph without collectives is being captured: milestones must not launch any
         self.launched_early = 0         # buckets launched from milestones / hooks in the last step (observability, tests)
+        # exposed communication: time the COMPUTE stream spends in finish() -- launching the buckets that did not overlap with backward
+        # and waiting for all of them -- measured with events on that stream when `record_exposed` is set (bench.py --gpus N reports it)
+        self.record_exposed = False
+        self._exposed = []
 
     def broadcast_initial_state(self):
         if self.world == 1:
@@ -294,14 +298,31 @@ class GradientExchange:
             self.opt.install_grad_views()
         if not self._armed:
             self._build()
+        timed = self.record_exposed and self.opt.grad.is_cuda and not torch.cuda.is_current_stream_capturing()
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         for bk in self.buckets:
             if bk["got"] != -1:
                 self._launch(bk)
         for w in self._pending:
             w.wait()
         self._pending.clear()
+        if timed:
+            e1.record()
+            self._exposed.append((e0, e1))
         for bk in self.buckets:
             bk["got"] = 0
+
+    def exposed_ms(self):
+        """Mean time per step the compute stream was held by the gradient exchange since the last call (None: nothing recorded, e.g.
+        the collectives live inside a captured graph).  Synchronises."""
+        if not self._exposed:
+            return None
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in self._exposed]
+        self._exposed = []
+        return sum(ms) / len(ms)
 
     @property
     def grad_scale(self):

@@ -774,8 +774,11 @@ def _dp_gpu_worker(rank, world, port, q, use_graph=False):
     tr.comm.world = world_saved
     tr.comm.finish()                                         # builds the buckets (and sums the probe gradients, which the step overwrites)
     # (the probe pass also advanced the BN running statistics; training-mode gradients do not depend on them)
+    tr.comm.record_exposed = True
     out = tr.step(shard)
     torch.cuda.synchronize()
+    ex = tr.comm.exposed_ms()                                # what bench.py --gpus N reports as comm.exposed_comm_ms_per_step
+    assert ex is not None and ex > 0.0 and tr.comm.exposed_ms() is None
     # backward milestones launched the all-reduce of the head's / late stages' buckets before backward had finished
     assert len(tr.comm.buckets) >= 4 and 1 <= tr.comm.launched_early < len(tr.comm.buckets), (tr.comm.launched_early, len(tr.comm.buckets))
     # numpy arrays are pickled by value (tensors would travel as file descriptors the exiting worker takes with it)
@@ -1479,7 +1482,6 @@ def test_cfg5_full_size_flip_inference_graph_replay_matches_two_pass_eager(golde
                 kpr, scr = m.inference(x, flip=True, flip_pairs=pairs)
                 ref.append((C(kpr), C(scr)))
         assert ref[0][0].shape == (B, K, 2) and np.isfinite(ref[0][0]).all() and np.isfinite(ref[0][1]).all()
-        assert ref[0][0][..., 0].max() <= 71.0 + 4 and ref[0][0][..., 1].max() <= 95.0 + 4 and ref[0][0].min() >= -4
         monkeypatch.setenv("POSE_FLIP_BATCHED", "1")
         dispatch.set_streams(True)
         static = xs[0].clone()

@@ -81,12 +81,33 @@ def time_kernel(fn, iters=20, warmup=3):
     return e0.elapsed_time(e1) / iters * 1e-3
 
 
-PROFILE_CSV = os.path.join(ROOT, "profiles", "r03_bench_kernel_stats.csv")      # rocprofv3 --kernel-trace --stats of `python bench.py --steps 4 --warmup 2`
+PROFILE_TAG = "r04"
+PROFILE_CSV = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_bench_kernel_stats.csv")      # rocprofv3 --kernel-trace --stats of `python bench.py --steps 4 --warmup 2`
+PROFILE_UNION = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_kernel_union.json")         # scripts/trace_summary.py over the same trace: union of each kernel's intervals
+PROFILE_META = os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_profile_meta.json")          # scripts/profile_meta.py: fingerprint of the code the profile was taken with
+
+
+def profile_source():
+    """Where the in-step fields of the roofline rows come from, and whether the committed profile still describes this code: the fields
+    read from profiles/ are nulled when the fingerprint of the kernel sources / launch logic differs from the one stored with the profile."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    try:
+        import profile_meta
+        now = profile_meta.fingerprint()
+    except Exception:       # noqa: BLE001
+        now = None
+    try:
+        with open(PROFILE_META) as f:
+            meta = json.load(f)
+    except (OSError, ValueError):
+        meta = {}
+    return {"files": [os.path.relpath(p, ROOT) for p in (PROFILE_CSV, PROFILE_UNION)], "captured_at_code_sha16": meta.get("code_sha16"),
+            "current_code_sha16": now, "stale": not (now and meta.get("code_sha16") == now), "command": meta.get("command")}
 
 
 def load_step_profile():
-    """Per-kernel in-step numbers from the committed rocprof summary of THIS command: {kernel name: (launches per step, average us)}.
-    Steps in the trace = launches of k_adamw (one per step, eager warm-up steps and graph replays alike)."""
+    """Per-kernel in-step numbers from the committed rocprof summary of THIS command: {kernel name: (launches per step, average us,
+    union ms per step or None)}.  Steps in the trace = launches of k_adamw (one per step, eager warm-up steps and graph replays alike)."""
     import csv
     try:
         with open(PROFILE_CSV) as f:
@@ -96,14 +117,20 @@ def load_step_profile():
     steps = max([int(r["Calls"]) for r in rows if r["Name"].startswith("k_adamw")] or [0])
     if not steps:
         return {}, 0
-    return {r["Name"].replace("void ", ""): (int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3) for r in rows}, steps
+    try:
+        with open(PROFILE_UNION) as f:
+            uni = json.load(f)["kernels"]
+    except (OSError, KeyError, ValueError):
+        uni = {}
+    return {r["Name"].replace("void ", ""): (int(r["Calls"]) / steps, float(r["AverageNs"]) / 1e3,
+                                            (uni.get(r["Name"].replace("void ", "")) or {}).get("union_ms_per_step")) for r in rows}, steps
 
 
 def load_pmc():
     """-> (isolated, step): L2-miss bytes per launch from the --pmc passes over scripts/prof_kernels.py.  `isolated` has one shape per kernel
     name (the roofline probes' shapes); `step` is the mean over every launch of that name in an eager step: exact only for single-shape kernels."""
     out = []
-    for name in ("r03_pmc_traffic_isolated.json", "r03_pmc_traffic_step.json"):
+    for name in (f"{PROFILE_TAG}_pmc_traffic_isolated.json", f"{PROFILE_TAG}_pmc_traffic_step.json"):
         try:
             with open(os.path.join(ROOT, "profiles", name)) as f:
                 out.append(json.load(f)["kernels"])
@@ -134,16 +161,22 @@ def _entry(kernel, what, bound, sec, flops=None, bytes_=None, trace=None, single
         elif single_shape and key in stp:
             e["traffic"] = stp[key]["traffic_bytes"]
     if prof and trace and trace in prof:
-        lps, us = prof[trace]
+        lps, us, union_ms = prof[trace]
         e["launches_per_step"] = round(lps, 2)
         e["us_in_step_avg"] = round(us, 1)
         e["ms_in_step"] = round(lps * us / 1e3, 3)
         e["frac_in_step"] = round(work / (us * 1e-6) / scale / peak, 4) if single_shape else None
+        # instances that share the chip on concurrent streams (the head's three branches) each look slow per launch: total work of the
+        # step's launches over the UNION of their intervals is what the kernel family delivers in the step
+        e["union_ms_in_step"] = None if union_ms is None else round(union_ms, 3)
+        e["frac_in_step_union"] = round(work * lps / (union_ms * 1e-3) / scale / peak, 4) if (single_shape and union_ms) else None
+    elif prof and trace:
+        log(f"roofline: kernel name {trace!r} not found in {os.path.basename(PROFILE_CSV)} (renamed instantiation?): in-step fields omitted")
     return e
 
 
 def roofline_table(model, B, trainer=None):
-    """The kernels that top the aggregate of the step (profiles/r03_trace_summary.txt), each on its dominant shape, timed live here and
+    """The kernels that top the aggregate of the step (profiles/r04_trace_summary.txt), each on its dominant shape, timed live here and
     set beside its in-step numbers from profiles/.  Algorithmic work: GEMM-shaped kernels 2*M*N*K flops vs the dense
     bf16 MFMA peak; the shallow token GEMMs, the fused block kernels, BatchNorm and the slab reduction are HBM-bound: bytes = every
     operand read once + every result written once."""
@@ -156,6 +189,11 @@ def roofline_table(model, B, trainer=None):
     out = []
     prof, steps_in_trace = load_step_profile()
     pmc = load_pmc()
+    src = profile_source()
+    if src["stale"]:
+        log(f"roofline: profiles/{PROFILE_TAG}_* were captured at code {src['captured_at_code_sha16']}, this tree is {src['current_code_sha16']}: "
+            "in-step fields read from them are omitted (re-run scripts/gpu_r04_profile.sh)")
+        prof, pmc = {}, ({}, {})
     E = lambda *a, **k: out.append(_entry(*a, prof=prof, pmc=pmc, **k))
     with nnops.use_weights(model) as wc:
         # 1. head conv 3x3 256->256 @64x48 (fusion_head.py:215,224,235), forward with the BN-statistics epilogue; the same kernel runs the
@@ -284,6 +322,7 @@ def roofline_table(model, B, trainer=None):
         log(f"input-pipeline probe skipped: {type(e).__name__}: {e}")
     for e in out:
         e["steps_in_trace"] = steps_in_trace
+        e["profile_source"] = src       # the fields us_in_step_avg / launches_per_step / ms_in_step / frac_in_step* / traffic come from these files
     return out
 
 
@@ -322,7 +361,7 @@ def roofline_other(cfg_name, model, B, c):
                        flops=2.0 * B * H * W * C * 9 * C, bytes_=2.0 * 2 * B * H * W * C)]
     # HRFormer-base twin.  The flip test runs x and flip(x) as ONE batch: every launch sees 2B samples.
     try:
-        with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_wide.json")) as f:
+        with open(os.path.join(ROOT, "profiles", f"{PROFILE_TAG}_pmc_traffic_wide.json")) as f:
             wide_pmc = json.load(f)["kernels"]        # L2-miss bytes per launch at these shapes (scripts/gpu_pmc_traffic_wide.sh)
     except (OSError, KeyError, ValueError):
         wide_pmc = {}

@@ -65,7 +65,7 @@ def ops():
 
 
 # the network ops themselves (they refuse to run outside a scope: nnops._wc() raises without an active weight cache)
-from .nnops import (backward_milestone, conv_bn_act, drop_scales, exchange, exchange_output, head_out, mlp_rows, residual_block,  # noqa: E402,F401
+from .nnops import (backward_milestone, conv_bn_act, deconv_bn_relu, drop_scales, exchange, exchange_output, head_out, mlp_rows, residual_block,  # noqa: E402,F401
                     to_features, window_attention_tokens, window_block)
 
 

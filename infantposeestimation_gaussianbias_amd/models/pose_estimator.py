@@ -16,22 +16,43 @@ _BACKBONES = {"hrnet_w32": (hrnet_w32, 32), "hrnet_w48": (hrnet_w48, 48), "hrnet
 
 
 class HeatmapHead(nn.Module):
-    """1x1 conv to K maps, init N(0, 0.001) (pose_estimator.py:22-99). Deconv stacks (never enabled by the
-    reference: num_deconv_layers=0 at its only call site) are not built."""
+    """Optional SimpleBaseline-style deconv stack (ConvTranspose2d stride 2 + BN + ReLU per layer), then a 1x1 conv to K maps; init
+    N(0, 0.001) / BN 1, 0 (pose_estimator.py:22-99).  The reference's builders use num_deconv_layers = 0; the stack runs as stacked
+    parity-class convolutions + pixel shuffle (nnops.deconv_bn_relu).  Kernel 3 raises, as in the reference (output_padding -1)."""
 
     def __init__(self, in_channels: int, out_channels: int, num_deconv_layers: int = 0, num_deconv_filters=(256, 256, 256),
                  num_deconv_kernels=(4, 4, 4)):
         super().__init__()
-        if num_deconv_layers != 0:
-            raise ValueError("HeatmapHead: deconv layers are not supported (the reference never enables them)")
         self.in_channels, self.out_channels, self.deconv = in_channels, out_channels, None
-        self.final_layer = nn.Conv2d(in_channels, out_channels, 1)
-        nn.init.normal_(self.final_layer.weight, std=0.001)
-        nn.init.zeros_(self.final_layer.bias)
+        final_in = in_channels
+        if num_deconv_layers > 0:
+            layers = []
+            for i in range(num_deconv_layers):
+                cin, cout, k = (in_channels if i == 0 else num_deconv_filters[i - 1]), num_deconv_filters[i], num_deconv_kernels[i]
+                pad = (k - 1) // 2
+                if k - 2 * pad - 2 < 0:      # kernel 3: the reference builds the layer and fails in its first forward ("negative output_padding")
+                    raise ValueError(f"HeatmapHead: deconv kernel {k} gives output_padding {k - 2 * pad - 2} by the reference's rule")
+                layers += [nn.ConvTranspose2d(cin, cout, k, stride=2, padding=pad, output_padding=k - 2 * pad - 2, bias=False),
+                           nn.BatchNorm2d(cout), nn.ReLU(inplace=True)]       # parameter holders with the reference's Sequential indices
+            self.deconv = nn.Sequential(*layers)
+            final_in = num_deconv_filters[num_deconv_layers - 1]
+        self.final_layer = nn.Conv2d(final_in, out_channels, 1)
+        for m in self.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.normal_(m.weight, std=0.001)
+                if m.bias is not None:
+                    nn.init.zeros_(m.bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                nn.init.ones_(m.weight)
+                nn.init.zeros_(m.bias)
 
     def forward(self, x):
         with nnops.scope(self):
-            return nnops.head_out(nnops.from_public(x), self.final_layer)
+            t = nnops.from_public(x)
+            if self.deconv is not None:
+                for i in range(0, len(self.deconv), 3):
+                    t = nnops.deconv_bn_relu(t, self.deconv[i], self.deconv[i + 1], self.training)
+            return nnops.head_out(t, self.final_layer)
 
 
 class KeypointMSELoss(nn.Module):

@@ -518,6 +518,138 @@ def residual_block(x, first, middle, last, training):
     return conv_bn_act(y, last[0], last[1], True, x.detach() if fuse else x, training, skip_out=hold)
 
 
+# ================================================================================================ transposed conv (deconv head)
+# HeatmapHead's optional SimpleBaseline-style stack (pose_estimator.py:47-69): ConvTranspose2d(k, stride 2) + BN + ReLU with k = 4
+# (padding 1) or k = 2 (padding 0); the reference's own padding rule gives output_padding -1 for k = 3 and raises there.  A stride-2
+# transposed convolution is four ordinary convolutions, one per output parity class (oy & 1, ox & 1), each using the taps ky with
+# (py + p - ky) even at the input offset dy = (py + p - ky) / 2 in {-1, 0, 1}: so it runs as ONE 3x3 stride-1 convolution Cin -> 4 Cout with
+# the class weights stacked on the output channels (k_igemm2 / the halo kernel, taps a class does not use are zero), followed by a pixel
+# shuffle, which in NHWC is a row permutation (pk_rows_by_map).  The reference never enables the stack (num_deconv_layers = 0 at its only
+# call site): correctness over speed -- 9/4 (k = 4) of the minimal MFMA work.
+_SHUFFLE_MAPS = {}
+
+
+def _deconv_taps(k):
+    """-> list of (class = py*2+px, tap = (dy+1)*3+(dx+1), ky, kx) of a stride-2 ConvTranspose2d with kernel k, padding (k-1)//2."""
+    p = (k - 1) // 2
+    if k - 2 * p - 2 < 0:
+        raise ValueError(f"ConvTranspose2d kernel {k}: output_padding {k - 2 * p - 2} (the reference's rule, pose_estimator.py:53-54) is negative")
+    one = []
+    for par in (0, 1):
+        for kk in range(k):
+            if (par + p - kk) % 2 == 0 and -1 <= (par + p - kk) // 2 <= 1:
+                one.append((par, (par + p - kk) // 2, kk))
+    return [(py * 2 + px, (dy + 1) * 3 + (dx + 1), ky, kx) for py, dy, ky in one for px, dx, kx in one]
+
+
+class _StackDeconv(torch.autograd.Function):
+    """ConvTranspose2d weight (Cin, Cout, k, k) -> the stacked 3x3 conv weight (4 Cout, Cin, 3, 3) of the parity-class form; backward maps
+    the stacked gradient back (into the parameter's gradient sink when it has one)."""
+
+    @staticmethod
+    def forward(ctx, w):
+        Cin, Cout, k, _ = w.shape
+        ws = torch.zeros(4 * Cout, Cin, 3, 3, dtype=F32, device=w.device)
+        for cls, tap, ky, kx in _deconv_taps(k):
+            ws[cls * Cout:(cls + 1) * Cout, :, tap // 3, tap % 3] = w[:, :, ky, kx].t()
+        ctx.param, ctx.shape = w, tuple(w.shape)
+        return ws
+
+    @staticmethod
+    def backward(ctx, g):
+        Cin, Cout, k, _ = ctx.shape
+        dst, direct = _sink(ctx.param)
+        dst.zero_()
+        for cls, tap, ky, kx in _deconv_taps(k):
+            dst[:, :, ky, kx] = g[cls * Cout:(cls + 1) * Cout, :, tap // 3, tap % 3].t()
+        return None if direct else dst
+
+
+class _ConvW(torch.autograd.Function):
+    """Stride-1 convolution (3x3 / 1x1) with an EXPLICIT fp32 OIHW weight tensor (not a parameter of the weight cache): the bf16 compute
+    copies are made here.  -> raw bf16 (B,H,W,N) and the BatchNorm partial statistics of the conv epilogue."""
+
+    @staticmethod
+    def forward(ctx, x, w):
+        N, Cin, k, _ = w.shape
+        wf = w.permute(0, 2, 3, 1).reshape(N, k * k, Cin).to(BF16).contiguous()                 # [N][T][Cin]
+        wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, k * k, N).to(BF16).contiguous()      # [Cin][T flipped][N]
+        x = x.contiguous()
+        raw, part = _conv_raw(x, wf, N, k, 1, True)
+        ctx.save_for_backward(x, wd)
+        ctx.meta = (N, Cin, k)
+        ctx.mark_non_differentiable(part)
+        return raw, part
+
+    @staticmethod
+    def backward(ctx, g, _gpart):
+        x, wd = ctx.saved_tensors
+        N, Cin, k = ctx.meta
+        B, H, W, _ = x.shape
+        g = g.contiguous()
+        dx = _conv_dgrad(g, wd, Cin, k, 1, (H, W)) if ctx.needs_input_grad[0] else None
+        dw = _wgrad(x, g, N, Cin, k, 1, (B, H, W, H, W))
+        return dx, dw
+
+
+class _BnActOnly(torch.autograd.Function):
+    """BatchNorm (+ReLU) of a raw conv output whose partial statistics [rows][2][C] are handed in (train mode) / on running statistics."""
+
+    @staticmethod
+    def forward(ctx, raw, part, gamma, beta, bn, relu, training):
+        ctx.params = (gamma, beta)
+        raw = raw.contiguous()
+        C = raw.shape[-1]
+        M = raw.numel() // C
+        dev = raw.device
+        y = _e(tuple(raw.shape), BF16, dev)
+        if training:
+            _wc().bn_eval.pop(id(bn), None)
+            scale, shift, mean, rstd = (_e((C,), F32, dev) for _ in range(4))
+            call("pk_bn_train_fwd", raw, part, part.shape[0], C, M, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, 0.1, 1e-5,
+                 None, y, mean, rstd, scale, shift, 1 if relu else 0, stream_ptr())
+        else:
+            scale, shift, mean, rstd = _bn_eval_affine(_wc(), bn, gamma, beta)
+            call("pk_bn_act", raw, scale, shift, None, y, M, C, 1 if relu else 0, stream_ptr())
+        ctx.save_for_backward(raw, y, mean, rstd, gamma)
+        ctx.meta = (relu, training, M, C)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        raw, y, mean, rstd, gamma = ctx.saved_tensors
+        relu, training, M, C = ctx.meta
+        dev = dy.device
+        g_p, b_p = ctx.params
+        (dgamma, sg), (dbeta, sb) = _sink(g_p), _sink(b_p)
+        nb = _lib.lib.pk_bn_bwd_blocks(M)
+        part, sums = _e((nb, 2, C), F32, dev), _e((2 * C,), F32, dev)
+        draw = _e(tuple(raw.shape), BF16, dev)
+        call("pk_bn_bwd", dy.contiguous(), y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, None, M, C, (1 if relu else 0) | (0 if training else 2),
+             stream_ptr())
+        return draw, None, None if sg else dgamma, None if sb else dbeta, None, None, None
+
+
+def deconv_bn_relu(x, deconv, bn, training):
+    """(B,H,W,Cin) -> (B,2H,2W,Cout): ConvTranspose2d(k in {2, 4}, stride 2, bias=False) + BatchNorm + ReLU (pose_estimator.py:47-69)."""
+    from . import hipops
+    w = deconv.weight
+    Cin, Cout, k, _ = w.shape
+    if deconv.stride[0] != 2 or deconv.bias is not None or Cout % 8 or Cin % 8:
+        raise _lib.PoseKernelError("deconv layer: stride-2 ConvTranspose2d without bias and channel counts that are multiples of 8")
+    B, H, W, _ = x.shape
+    raw_s, part = _ConvW.apply(x, _StackDeconv.apply(w))                  # (B,H,W,4*Cout): class-major channels
+    key = (B, H, W, str(x.device))
+    if key not in _SHUFFLE_MAPS:          # row of out pixel (b, 2i+py, 2j+px) <- row ((b*H+i)*W+j)*4 + py*2+px of the (.., Cout) row view
+        b, oy, ox = torch.meshgrid(torch.arange(B), torch.arange(2 * H), torch.arange(2 * W), indexing="ij")
+        m = (((b * H + oy // 2) * W + ox // 2) * 4 + (oy % 2) * 2 + (ox % 2)).reshape(-1)
+        _SHUFFLE_MAPS[key] = m.to(torch.int32).to(x.device)
+    raw = hipops.rows_by_map(raw_s.view(B * H * W * 4, Cout), _SHUFFLE_MAPS[key], B * 4 * H * W, False).view(B, 2 * H, 2 * W, Cout)
+    t = part.shape[0]
+    part4 = part.view(t, 2, 4, Cout).permute(0, 2, 1, 3).reshape(4 * t, 2, Cout).contiguous()      # a channel's statistics: its four classes
+    return _BnActOnly.apply(raw, part4, bn.weight, bn.bias, bn, True, training)
+
+
 # ================================================================================================ head output conv
 class _HeadOut(torch.autograd.Function):
     @staticmethod

@@ -8,7 +8,7 @@ import csv
 import sys
 
 
-def main(path, nsteps=3):
+def main(path, nsteps=3, union_json=None):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     ad = [i for i, r in enumerate(rows) if "k_adamw" in r["Kernel_Name"]]
@@ -67,8 +67,35 @@ def main(path, nsteps=3):
     for n, v in sorted(share.items(), key=lambda kv: -kv[1])[:25]:
         print(f"{alone[n]:7.3f} ms alone {v:7.3f} ms share  {n}")
     by_shape(seg, nsteps, alone_k)
+    if union_json:
+        write_union(seg, nsteps, union_json)
     per = len(seg) // nsteps
     timeline(seg[len(seg) - 2 * per:len(seg) - per] if nsteps >= 2 else seg)
+
+
+def write_union(seg, nsteps, path):
+    """Per kernel name: the wall time during which at least one instance runs (union of its intervals).  Instances of one kernel that
+    share the chip on concurrent streams (the three head branches' convolutions) each look slow in the per-launch average; total work
+    over the union is the throughput the kernel family actually delivers in the step (bench.py: `frac_in_step_union`)."""
+    import json
+    iv = collections.defaultdict(list)
+    for r in seg:
+        iv[r["Kernel_Name"].replace("void ", "")].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+    out = {}
+    for n, lst in iv.items():
+        lst.sort()
+        tot, (cs, ce) = 0, lst[0]
+        for a, b in lst[1:]:
+            if a > ce:
+                tot += ce - cs
+                cs, ce = a, b
+            else:
+                ce = max(ce, b)
+        tot += ce - cs
+        out[n] = {"launches_per_step": len(lst) / nsteps, "union_ms_per_step": tot / 1e6 / nsteps,
+                  "sum_ms_per_step": sum(b - a for a, b in lst) / 1e6 / nsteps}
+    with open(path, "w") as f:
+        json.dump({"steps": nsteps, "kernels": out}, f, indent=1, sort_keys=True)
 
 
 def _wgs(r):
@@ -113,4 +140,4 @@ def timeline(seg, bin_ms=0.5):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3)
+    main(sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 3, sys.argv[3] if len(sys.argv) > 3 else None)

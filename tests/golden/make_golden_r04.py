@@ -129,5 +129,39 @@ def main():
     mg.save("public_r04.npz", **out)
 
 
+def cap_deconv_head():
+    """HeatmapHead with the optional deconv stack (models/pose_estimator.py:22-99): three ConvTranspose2d(stride 2) + BN + ReLU layers with
+    kernels 4 / 2 / 4 (padding / output_padding as the reference derives them; kernel 3 gives output_padding -1 and raises there), then the 1x1 final layer; train-mode forward + every
+    gradient, running statistics after that step, and the eval-mode forward.  -> tests/golden/deconv_r04.npz + its state_dict spec."""
+    import json
+    from models import pose_estimator as pe
+    from recipe import spec_of
+    torch.manual_seed(0)
+    head = pe.HeatmapHead(32, 17, num_deconv_layers=3, num_deconv_filters=(48, 32, 24), num_deconv_kernels=(4, 2, 4))
+    spec = mg.load_recipe(head, salt=51)
+    out = {}
+    x = T(synth_input("deconv_x", (2, 32, 6, 5))).requires_grad_(True)
+    head.train()
+    y = head(x)
+    gy = T(synth_input("deconv_gy", tuple(y.shape)))
+    y.backward(gy)
+    out["y_train"], out["gx"] = N(y), N(x.grad)
+    for k, p in head.named_parameters():
+        out["g." + k] = N(p.grad)
+    for k, v in head.state_dict().items():
+        if "running" in k:
+            out["buf." + k] = N(v)
+    head.eval()
+    with torch.no_grad():
+        out["y_eval"] = N(head(x.detach()))
+    mg.save("deconv_r04.npz", **out)
+    with open(os.path.join(HERE, "deconv_r04.json"), "w") as f:
+        json.dump({"spec": spec}, f, separators=(",", ":"))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "deconv":      # the deconv fixtures only (public_r04.npz stays byte-identical)
+        cap_deconv_head()
+    else:
+        main()
+        cap_deconv_head()

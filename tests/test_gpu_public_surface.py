@@ -155,3 +155,31 @@ def test_hrnet_w48_eval_vs_golden(golden):
         kp, sc = m.inference(x, flip=False)
     assert rel_err(C(o["heatmaps"]), z["w48_eval_hm"]) < 3e-2
     assert kp.shape == (1, 17, 2) and rel_err(C(sc), z["w48_eval_sc"]) < 3e-2       # (arg-max positions of a random-weight net are not stable under bf16)
+
+
+def test_heatmap_head_deconv_stack_vs_reference(golden):
+    """HeatmapHead(num_deconv_layers=3, kernels 4 / 2 / 4) (pose_estimator.py:22-99; VERDICT r03 "missing" #5): train-mode forward, input and
+    parameter gradients, running statistics and the eval-mode forward against the reference's own vectors; state_dict keys as the reference's
+    nn.Sequential gives them.  bf16 activations through three deconv + BN layers: norm-wise 3e-2 (BatchNorm over 2 x 48..1920 samples)."""
+    from infantposeestimation_gaussianbias_amd.models.pose_estimator import HeatmapHead
+    z, spec = golden("deconv_r04.npz"), golden("deconv_r04.json")["spec"]
+    head = HeatmapHead(32, 17, num_deconv_layers=3, num_deconv_filters=(48, 32, 24), num_deconv_kernels=(4, 2, 4))
+    assert list(head.state_dict()) == list(spec)
+    head.load_state_dict({k: torch.from_numpy(v) for k, v in synth_state_dict(spec, 51).items()}, strict=True)
+    head = head.to(DEV).train()
+    x = G(synth_input("deconv_x", (2, 32, 6, 5)), True)
+    y = head(x)
+    assert tuple(y.shape) == (2, 17, 48, 40) and rel_err(C(y), z["y_train"]) < 3e-2
+    y.backward(G(synth_input("deconv_gy", tuple(y.shape))))
+    l2 = lambda a, b: float(np.linalg.norm(np.asarray(a, np.float64) - b) / max(np.linalg.norm(b), 1e-30))
+    assert l2(C(x.grad), z["gx"]) < 6e-2
+    for k, p in head.named_parameters():
+        assert p.grad is not None and l2(C(p.grad), z["g." + k]) < 6e-2, (k, l2(C(p.grad), z["g." + k]))
+    sd = head.state_dict()
+    for k in z:
+        if k.startswith("buf."):
+            assert rel_err(C(sd[k[4:]]), z[k]) < 2e-2, k
+    with torch.no_grad():
+        assert rel_err(C(head.eval()(x.detach())), z["y_eval"]) < 3e-2
+    with pytest.raises(ValueError):
+        HeatmapHead(32, 17, num_deconv_layers=1, num_deconv_filters=(32,), num_deconv_kernels=(3,))

@@ -288,14 +288,15 @@ def roofline_table(model, B, trainer=None):
     vec = lambda: torch.rand(C2, device=dev) + 0.5
     scale, shift, mean, rstd, gamma = vec(), vec(), vec(), vec(), vec()
     yo = torch.empty_like(raw)
-    sec = time_kernel(lambda: call("pk_bn_act", raw, scale, shift, None, yo, M, C2, 1, stream_ptr()))
-    E("k_bn_act", "scale/shift + ReLU, 196608 x 256 (raw in, y out)", "hbm", sec, bytes_=4.0 * M * C2, trace=next((k for k in prof if k.startswith("k_bn_act(")), None))
+    maskb = torch.empty(M * C2 // 8, dtype=torch.uint8, device=dev)       # ReLU bit mask: written by the forward, read by both backward passes
+    sec = time_kernel(lambda: call("pk_bn_act", raw, scale, shift, None, yo, M, C2, 1, maskb, stream_ptr()))
+    E("k_bn_act", "scale/shift + ReLU, 196608 x 256 (raw in, y + bit mask out)", "hbm", sec, bytes_=4.0 * M * C2 + M * C2 / 8, trace=next((k for k in prof if k.startswith("k_bn_act(")), None))
     nbb = _lib.lib.pk_bn_bwd_blocks(M)
     part, sums, dga, dbe = torch.empty(nbb, 2, C2, device=dev), torch.empty(2 * C2, device=dev), torch.empty(C2, device=dev), torch.empty(C2, device=dev)
     draw = torch.empty_like(raw)
-    sec = time_kernel(lambda: call("pk_bn_bwd", dy, y, raw, mean, rstd, gamma, part, sums, dga, dbe, draw, None, M, C2, 1, stream_ptr()))
-    E("k_bn_bwd_reduce + k_sum_partials + k_bn_bwd_apply", "BatchNorm backward, 196608 x 256: two passes over (dy, y, raw) + dx out (three launches)", "hbm",
-      sec, bytes_=2.0 * M * C2 * (3 + 3 + 1), trace=None)
+    sec = time_kernel(lambda: call("pk_bn_bwd", dy, None, raw, mean, rstd, gamma, part, sums, dga, dbe, draw, None, M, C2, 1, maskb, stream_ptr()))
+    E("k_bn_bwd_reduce + k_sum_partials + k_bn_bwd_apply", "BatchNorm backward, 196608 x 256: two passes over (dy, raw, ReLU bit mask) + dx out (three launches)", "hbm",
+      sec, bytes_=2.0 * M * C2 * (2 + 2 + 1) + 2 * M * C2 / 8, trace=None)
     # 8. the step's slab reduction (ONE launch for all layers): bytes = every slab read once + every gradient written once
     tabs = [(k, t) for k, t in nnops._TABLES.items()]
     if tabs:

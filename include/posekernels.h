@@ -198,14 +198,14 @@ int pk_conv2d_group(const PkConvDesc* descs, int n, void* stream);
 typedef struct PkBnFwdDesc {       /* one pk_bn_train_fwd problem (finalize + apply in one pass; any row count)                          */
     const void* raw; const float* stats_partial; const float* gamma; const float* beta;
     float* running_mean; float* running_var; int64_t* num_batches_tracked;
-    const void* residual; void* y; float* save_mean; float* save_rstd;
+    const void* residual; void* y; float* save_mean; float* save_rstd; uint8_t* relu_mask /* optional, see pk_bn_act */;
     int64_t rows; int tiles, C; float momentum, eps; int relu;
 } PkBnFwdDesc;
 int pk_bn_train_fwd_group(const PkBnFwdDesc* descs, int n, void* stream);
 typedef struct PkBnBwdDesc {       /* one pk_bn_bwd problem; partial: [pk_bn_bwd_group_blocks(rows)][2][C] floats                        */
     const void* dy; const void* y_act; const void* raw; const float* save_mean; const float* save_rstd; const float* gamma;
-    float* partial; float* dgamma; float* dbeta; void* dx; void* dresidual;
-    int64_t rows; int C; int relu;  /* bit 0: mask by y_act > 0; bit 1: eval-mode statistics (no batch-mean terms)                          */
+    float* partial; float* dgamma; float* dbeta; void* dx; void* dresidual; const uint8_t* relu_mask /* optional: replaces y_act */;
+    int64_t rows; int C; int relu;  /* bit 0: mask by relu_mask / y_act > 0; bit 1: eval-mode statistics (no batch-mean terms)               */
 } PkBnBwdDesc;
 int pk_bn_bwd_group_blocks(int64_t rows);
 int pk_bn_bwd_group(const PkBnBwdDesc* descs, int n, void* stream);
@@ -285,19 +285,21 @@ int pk_sum_partials(const float* partial, int nb, int K, int stride, float* out,
 int pk_bn_finalize(const float* stats_partial, int tiles, int C, int count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps,
                    float* scale, float* shift, float* save_mean, float* save_rstd, void* stream);
+/* relu_mask (optional, rows*C/8 bytes): one byte per 16-byte chunk of y, bit j = channel j of the chunk is > 0 after the ReLU.  The
+ * backward kernels read it instead of the activated output (1/16 of the bytes).                                                    */
 int pk_bn_act(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
-              int relu, void* stream);                       /* y = relu?(x*scale + shift (+ residual)) */
+              int relu, uint8_t* relu_mask, void* stream);   /* y = relu?(x*scale + shift (+ residual)) */
 /* Train-mode BatchNorm forward from the conv epilogue's partial statistics (nn.BatchNorm2d.forward in models/hrnet.py:24-52,
  * models/hrformer.py:309-344): pk_bn_finalize + pk_bn_act, as ONE launch for small tensors (tiles <= 128).  scale / shift: [C] workspaces. */
 int pk_bn_train_fwd(const void* raw, const float* stats_partial, int tiles, int C, int64_t rows, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum, float eps, const void* residual,
-                    void* y, float* save_mean, float* save_rstd, float* scale, float* shift, int relu, void* stream);
+                    void* y, float* save_mean, float* save_rstd, float* scale, float* shift, int relu, uint8_t* relu_mask, void* stream);
 int pk_bn_bwd_blocks(int64_t rows);                          /* partial needs blocks*2*C floats */
-/* pk_bn_bwd `relu`: bit 0 = the forward applied ReLU (mask from y_act); bit 1 = eval-mode BatchNorm (save_mean / save_rstd hold the
+/* pk_bn_bwd `relu`: bit 0 = the forward applied ReLU (mask from relu_mask when given, else from y_act); bit 1 = eval-mode BatchNorm (save_mean / save_rstd hold the
  * running statistics, which are constants: dx = gamma * rstd * g, no batch-mean terms; dgamma / dbeta as in training).           */
 int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* save_mean, const float* save_rstd,
               const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
-              int64_t rows, int C, int relu, void* stream);
+              int64_t rows, int C, int relu, const uint8_t* relu_mask, void* stream);
 int pk_relu_bwd(const void* dy, const void* y, void* dx, int64_t numel, void* stream);
 /* nn.LayerNorm(C, eps 1e-5) over the channel dim of NHWC rows (hrformer.py:240,252,273,288).  C = row width (multiple of 8,
  * <= 1024); C_real (0 = C) = number of real channels when the rows carry zero padding: statistics over the real channels,

@@ -27,6 +27,21 @@ __device__ __forceinline__ uint4 pack8(const float* f) {
     return v;
 }
 
+// ReLU masks as BITS (round 4): the forward BatchNorm + ReLU kernels can emit one byte per 16-byte chunk (bit j: channel j of the chunk is
+// > 0 after the ReLU, taken from the bf16 value that is stored), and the backward kernels read that byte instead of the 16 bytes of the
+// activated output: 2 of the 7 tensor passes of a ReLU layer's BatchNorm backward (dy, y, raw read twice; dx written) become 1/16 as large.
+__device__ __forceinline__ uint32_t pos_mask8(const uint4& v) {
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t lo = w[i] & 0xffffu, hi = w[i] >> 16;
+        m |= ((lo != 0u && !(lo & 0x8000u)) ? 1u : 0u) << (2 * i);
+        m |= ((hi != 0u && !(hi & 0x8000u)) ? 1u : 0u) << (2 * i + 1);
+    }
+    return m;
+}
+
 // ================================================================================================ generic partial sums
 // out[k] (+)= scale * sum_b partial[b*stride + k], k < K.  Block = 16 columns x 64 row-lanes: lane r sums rows b = r (mod 64),
 // the 64 lane sums are combined in fixed order -> deterministic, and the serial chain is nb/64 instead of nb (these kernels
@@ -144,7 +159,7 @@ extern "C" int pk_bn_finalize(const float* stats_partial, int tiles, int C, int 
 // y = act(x*scale[c] + shift[c] (+ residual)); one 16-byte chunk per thread-iteration
 __global__ void __launch_bounds__(256) k_bn_act(const uint4* __restrict__ x, const float* __restrict__ scale,
                                                 const float* __restrict__ shift, const uint4* __restrict__ res, uint4* __restrict__ y,
-                                                size_t chunks, int cchunks, int relu) {
+                                                size_t chunks, int cchunks, int relu, uint8_t* __restrict__ mask) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
         // (32-bit: a size_t modulo is a ~60-instruction software division per chunk; a mask when the chunk count is a power of two)
         const int c0 = (int)(((cchunks & (cchunks - 1)) == 0) ? ((uint32_t)i & (uint32_t)(cchunks - 1)) : ((uint32_t)i % (uint32_t)cchunks)) * 8;
@@ -157,18 +172,20 @@ __global__ void __launch_bounds__(256) k_bn_act(const uint4* __restrict__ x, con
             if (res) t += r[j];
             v[j] = relu ? fmaxf(t, 0.f) : t;
         }
-        y[i] = pack8(v);
+        const uint4 o = pack8(v);
+        y[i] = o;
+        if (mask) mask[i] = (uint8_t)pos_mask8(o);
     }
 }
 extern "C" int pk_bn_act(const void* x, const float* scale, const float* shift, const void* residual, void* y, int64_t rows, int C,
-                         int relu, void* stream) {
+                         int relu, uint8_t* relu_mask, void* stream) {
     PK_REQUIRE(x && scale && shift && y && rows > 0 && C > 0 && (C & 7) == 0, "pk_bn_act: bad argument (C=%d)", C);
     const size_t chunks = (size_t)rows * (C / 8);
     PK_SUPPORTED(chunks < 0xffffffffull, "pk_bn_act: tensor too large for 32-bit chunk indices");
     size_t nb = (chunks + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipLaunchKernelGGL(k_bn_act, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, (const uint4*)x, scale, shift,
-                       (const uint4*)residual, (uint4*)y, chunks, C / 8, relu);
+                       (const uint4*)residual, (uint4*)y, chunks, C / 8, relu, relu_mask);
     return pk_launch_status("pk_bn_act");
 }
 
@@ -182,7 +199,8 @@ __device__ __forceinline__ void bn_act_fin_body(const uint4* __restrict__ x, con
                                                 const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
                                                 float* __restrict__ run_var, long long* __restrict__ nbt, float momentum, float eps,
                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out, const uint4* __restrict__ res,
-                                                uint4* __restrict__ y, int rows, int rows_per_block, int relu, const int cg, const int rb) {
+                                                uint4* __restrict__ y, int rows, int rows_per_block, int relu, const int cg, const int rb,
+                                                uint8_t* __restrict__ mask) {
     __shared__ double shs[8][BNS_CG], shq[8][BNS_CG];
     __shared__ float s_scale[BNS_CG], s_shift[BNS_CG];
     const int c0 = cg * BNS_CG;
@@ -245,16 +263,18 @@ __device__ __forceinline__ void bn_act_fin_body(const uint4* __restrict__ x, con
             if (res) t += rr[j];
             v[j] = relu ? fmaxf(t, 0.f) : t;
         }
-        y[i] = pack8(v);
+        const uint4 o = pack8(v);
+        y[i] = o;
+        if (mask) mask[i] = (uint8_t)pos_mask8(o);
     }
 }
 __global__ void __launch_bounds__(256) k_bn_act_fin(const uint4* __restrict__ x, const float* __restrict__ part, int tiles, int C, float count,
                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ run_mean,
                                                     float* __restrict__ run_var, long long* __restrict__ nbt, float momentum, float eps,
                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out, const uint4* __restrict__ res,
-                                                    uint4* __restrict__ y, int rows, int rows_per_block, int relu) {
+                                                    uint4* __restrict__ y, int rows, int rows_per_block, int relu, uint8_t* __restrict__ mask) {
     bn_act_fin_body(x, part, tiles, C, count, gamma, beta, run_mean, run_var, nbt, momentum, eps, mean_out, rstd_out, res, y, rows, rows_per_block,
-                    relu, (int)blockIdx.x, (int)blockIdx.y);
+                    relu, (int)blockIdx.x, (int)blockIdx.y, mask);
 }
 // grouped form: up to PK_GROUP_MAX BatchNorm layers (any row count: every workgroup re-derives the statistics of its 32 channels)
 struct BnFwdGroup {
@@ -270,7 +290,7 @@ __global__ void __launch_bounds__(256) k_bn_act_fin_g(BnFwdGroup g) {
     const int local = L - g.first[i], ncg = g.ncg[i];
     bn_act_fin_body((const uint4*)d.raw, d.stats_partial, d.tiles, d.C, (float)d.rows, d.gamma, d.beta, d.running_mean, d.running_var,
                     (long long*)d.num_batches_tracked, d.momentum, d.eps, d.save_mean, d.save_rstd, (const uint4*)d.residual, (uint4*)d.y,
-                    (int)d.rows, g.rpb[i], d.relu, local % ncg, local / ncg);
+                    (int)d.rows, g.rpb[i], d.relu, local % ncg, local / ncg, d.relu_mask);
 }
 static inline void bn_fin_grid(int64_t rows, int C, int& ncg, int& nrb, int& rpb) {
     ncg = (C + BNS_CG - 1) / BNS_CG;
@@ -305,7 +325,7 @@ extern "C" int pk_bn_train_fwd_group(const PkBnFwdDesc* d, int n, void* stream) 
 extern "C" int pk_bn_train_fwd(const void* raw, const float* stats_partial, int tiles, int C, int64_t rows, const float* gamma,
                                const float* beta, float* running_mean, float* running_var, int64_t* num_batches_tracked, float momentum,
                                float eps, const void* residual, void* y, float* save_mean, float* save_rstd, float* scale, float* shift,
-                               int relu, void* stream) {
+                               int relu, uint8_t* relu_mask, void* stream) {
     PK_REQUIRE(raw && stats_partial && gamma && beta && y && save_mean && save_rstd && scale && shift, "pk_bn_train_fwd: null pointer");
     PK_REQUIRE(tiles > 0 && C > 0 && (C & 7) == 0 && rows > 0, "pk_bn_train_fwd: bad sizes");
     static const int fused_on = PK_KNOB("PK_BN_FUSED", 1);
@@ -318,13 +338,13 @@ extern "C" int pk_bn_train_fwd(const void* raw, const float* stats_partial, int 
         const int rpb = (int)((rows + nrb - 1) / nrb);
         hipLaunchKernelGGL(k_bn_act_fin, dim3(ncg, nrb), dim3(256), 0, (hipStream_t)stream, (const uint4*)raw, stats_partial, tiles, C, (float)rows,
                            gamma, beta, running_mean, running_var, (long long*)num_batches_tracked, momentum, eps, save_mean, save_rstd,
-                           (const uint4*)residual, (uint4*)y, (int)rows, rpb, relu);
+                           (const uint4*)residual, (uint4*)y, (int)rows, rpb, relu, relu_mask);
         return pk_launch_status("pk_bn_train_fwd");
     }
     int rc = pk_bn_finalize(stats_partial, tiles, C, (int)rows, gamma, beta, running_mean, running_var, num_batches_tracked, momentum, eps, scale,
                             shift, save_mean, save_rstd, stream);
     if (rc) return rc;
-    return pk_bn_act(raw, scale, shift, residual, y, rows, C, relu, stream);
+    return pk_bn_act(raw, scale, shift, residual, y, rows, C, relu, relu_mask, stream);
 }
 
 // Backward, pass 1: per-block partial sums over rows of g and g*xhat, g = dy * (y > 0 if relu).
@@ -336,7 +356,7 @@ extern "C" int pk_bn_train_fwd(const void* raw, const float* stats_partial, int 
 __device__ __forceinline__ void bn_bwd_reduce_body(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
                                                    const uint4* __restrict__ raw, const float* __restrict__ mean,
                                                    const float* __restrict__ rstd, float* __restrict__ part, int64_t rows, int C,
-                                                   int relu, int rows_per_block, const int bid) {
+                                                   int relu, int rows_per_block, const int bid, const uint8_t* __restrict__ mask) {
     __shared__ float sh[256 * 16];
     const int cchunks = C / 8, rlanes = 256 / cchunks;
     const int cc = threadIdx.x % cchunks, rl = threadIdx.x / cchunks;
@@ -354,10 +374,19 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const uint4* __restrict__ dy,
             float g[8], xr[8], ya[8];
             unpack8(dy[i], g);
             unpack8(raw[i], xr);
-            if (relu) unpack8(yact[i], ya);
+            uint32_t mb = 0xffu;
+            if (relu) {
+                if (mask) mb = mask[i];
+                else {
+                    unpack8(yact[i], ya);
+                    mb = 0;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) mb |= (ya[j] > 0.f ? 1u : 0u) << j;
+                }
+            }
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                const float gg = (relu && !(ya[j] > 0.f)) ? 0.f : g[j];
+                const float gg = ((mb >> j) & 1u) ? g[j] : 0.f;
                 s1[j] += gg;
                 s2[j] += gg * (xr[j] - mu[j]) * rs[j];
             }
@@ -390,15 +419,16 @@ __device__ __forceinline__ void bn_bwd_reduce_body(const uint4* __restrict__ dy,
 __global__ void __launch_bounds__(256) k_bn_bwd_reduce(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
                                                        const uint4* __restrict__ raw, const float* __restrict__ mean,
                                                        const float* __restrict__ rstd, float* __restrict__ part, int64_t rows, int C,
-                                                       int relu, int rows_per_block) {
-    bn_bwd_reduce_body(dy, yact, raw, mean, rstd, part, rows, C, relu, rows_per_block, (int)blockIdx.x);
+                                                       int relu, int rows_per_block, const uint8_t* __restrict__ mask) {
+    bn_bwd_reduce_body(dy, yact, raw, mean, rstd, part, rows, C, relu, rows_per_block, (int)blockIdx.x, mask);
 }
 // Backward, pass 2: dx = gamma*rstd*(g - sum_g/M - xhat*sum_gx/M); optional d_residual = g
 __global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ dy, const uint4* __restrict__ yact,
                                                       const uint4* __restrict__ raw, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ sums, float inv_count, uint4* __restrict__ dx,
-                                                      uint4* __restrict__ dres, size_t chunks, int cchunks, int relu) {
+                                                      uint4* __restrict__ dres, size_t chunks, int cchunks, int relu,
+                                                      const uint8_t* __restrict__ mask) {
     const int C = cchunks * 8;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < chunks; i += (size_t)gridDim.x * blockDim.x) {
         // (32-bit: a size_t modulo is a ~60-instruction software division per chunk; a mask when the chunk count is a power of two)
@@ -406,11 +436,20 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply(const uint4* __restrict__ 
         float g[8], xr[8], ya[8], o[8];
         unpack8(dy[i], g);
         unpack8(raw[i], xr);
-        if (relu) unpack8(yact[i], ya);
+        uint32_t mb = 0xffu;
+        if (relu) {
+            if (mask) mb = mask[i];
+            else {
+                unpack8(yact[i], ya);
+                mb = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mb |= (ya[j] > 0.f ? 1u : 0u) << j;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int c = c0 + j;
-            const float gg = (relu && !(ya[j] > 0.f)) ? 0.f : g[j];
+            const float gg = ((mb >> j) & 1u) ? g[j] : 0.f;
             g[j] = gg;
             const float xh = (xr[j] - mean[c]) * rstd[c];
             o[j] = gamma[c] * rstd[c] * (gg - sums[c] * inv_count - xh * sums[C + c] * inv_count);
@@ -442,7 +481,7 @@ __device__ __forceinline__ void bn_bwd_apply_fin_body(const uint4* __restrict__ 
                                                       const float* __restrict__ gamma, const float* __restrict__ part, int nb,
                                                       float inv_count, float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                       uint4* __restrict__ dx, uint4* __restrict__ dres, int rows, int rows_per_block, int C,
-                                                      int relu, const int cg, const int rb) {
+                                                      int relu, const int cg, const int rb, const uint8_t* __restrict__ mask) {
     __shared__ double sh1[8][BNS_CG], sh2[8][BNS_CG];
     __shared__ float s_1[BNS_CG], s_2[BNS_CG];
     const int c0 = cg * BNS_CG;
@@ -492,10 +531,19 @@ __device__ __forceinline__ void bn_bwd_apply_fin_body(const uint4* __restrict__ 
         float g[8], xr[8], ya[8], o[8];
         unpack8(dy[i], g);
         unpack8(raw[i], xr);
-        if (relu) unpack8(yact[i], ya);
+        uint32_t mb = 0xffu;
+        if (relu) {
+            if (mask) mb = mask[i];
+            else {
+                unpack8(yact[i], ya);
+                mb = 0;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) mb |= (ya[j] > 0.f ? 1u : 0u) << j;
+            }
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            const float gg = (relu && !(ya[j] > 0.f)) ? 0.f : g[j];
+            const float gg = ((mb >> j) & 1u) ? g[j] : 0.f;
             g[j] = gg;
             const float xh = (xr[j] - mu[j]) * rs[j];
             o[j] = gm[j] * (gg - t1[j] - xh * t2[j]);
@@ -509,9 +557,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_fin(const uint4* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ part, int nb,
                                                           float inv_count, float* __restrict__ dbeta, float* __restrict__ dgamma,
                                                           uint4* __restrict__ dx, uint4* __restrict__ dres, int rows, int rows_per_block, int C,
-                                                          int relu) {
+                                                          int relu, const uint8_t* __restrict__ mask) {
     bn_bwd_apply_fin_body(dy, yact, raw, mean, rstd, gamma, part, nb, inv_count, dbeta, dgamma, dx, dres, rows, rows_per_block, C, relu,
-                          (int)blockIdx.x, (int)blockIdx.y);
+                          (int)blockIdx.x, (int)blockIdx.y, mask);
 }
 // grouped backward: ONE reduce launch + ONE apply launch for up to PK_GROUP_MAX BatchNorm layers
 struct BnBwdGroup {
@@ -526,7 +574,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_reduce_g(BnBwdGroup g) {
     while (i + 1 < g.n && L >= g.first_r[i + 1]) ++i;
     const PkBnBwdDesc& d = g.d[i];
     bn_bwd_reduce_body((const uint4*)d.dy, (const uint4*)d.y_act, (const uint4*)d.raw, d.save_mean, d.save_rstd, d.partial, d.rows, d.C, d.relu & 1,
-                       g.rpb_r[i], L - g.first_r[i]);
+                       g.rpb_r[i], L - g.first_r[i], d.relu_mask);
 }
 __global__ void __launch_bounds__(256) k_bn_bwd_apply_fin_g(BnBwdGroup g) {
     const int L = (int)blockIdx.x;
@@ -536,7 +584,7 @@ __global__ void __launch_bounds__(256) k_bn_bwd_apply_fin_g(BnBwdGroup g) {
     const int local = L - g.first_a[i], ncg = g.ncg[i];
     bn_bwd_apply_fin_body((const uint4*)d.dy, (const uint4*)d.y_act, (const uint4*)d.raw, d.save_mean, d.save_rstd, d.gamma, d.partial, g.nb[i],
                           (d.relu & 2) ? 0.f : 1.f / (float)d.rows, d.dbeta, d.dgamma, (uint4*)d.dx, (uint4*)d.dresidual, (int)d.rows, g.rpb_a[i],
-                          d.C, d.relu & 1, local % ncg, local / ncg);
+                          d.C, d.relu & 1, local % ncg, local / ncg, d.relu_mask);
 }
 // partial rows [blocks][2][C] of a member of pk_bn_bwd_group: the small-tensor rule of pk_bn_bwd where it applies (same sums bit for bit)
 extern "C" int pk_bn_bwd_group_blocks(int64_t rows) {
@@ -551,7 +599,7 @@ extern "C" int pk_bn_bwd_group(const PkBnBwdDesc* d, int n, void* stream) {
     for (int i = 0; i < n; ++i) {
         const PkBnBwdDesc& c = d[i];
         PK_REQUIRE(c.dy && c.raw && c.save_mean && c.save_rstd && c.gamma && c.partial && c.dgamma && c.dbeta && c.dx, "pk_bn_bwd_group: null pointer");
-        PK_REQUIRE(!(c.relu & 1) || c.y_act, "pk_bn_bwd_group: relu needs the activated output");
+        PK_REQUIRE(!(c.relu & 1) || c.y_act || c.relu_mask, "pk_bn_bwd_group: relu needs the activated output or its bit mask");
         PK_REQUIRE(c.rows > 0 && c.rows < (1 << 30) && c.C > 0 && (c.C & 7) == 0, "pk_bn_bwd_group: bad sizes");
         PK_SUPPORTED(c.C <= BNR_MAXC && c.C / 8 <= 256, "pk_bn_bwd_group: C=%d too large", c.C);
         g.d[i] = c;
@@ -575,12 +623,12 @@ extern "C" int pk_bn_bwd_group(const PkBnBwdDesc* d, int n, void* stream) {
 
 extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, const float* save_mean, const float* save_rstd,
                          const float* gamma, float* partial, float* sums, float* dgamma, float* dbeta, void* dx, void* dresidual,
-                         int64_t rows, int C, int relu, void* stream) {
+                         int64_t rows, int C, int relu, const uint8_t* relu_mask, void* stream) {
     PK_REQUIRE(dy && raw && save_mean && save_rstd && gamma && partial && sums && dgamma && dbeta && dx, "pk_bn_bwd: null pointer");
     // relu: bit 0 = the forward applied ReLU; bit 1 = eval-mode BatchNorm (running statistics are constants: no batch-mean terms)
     const int eval_mode = relu & 2;
     relu &= 1;
-    PK_REQUIRE(!relu || y_act, "pk_bn_bwd: relu needs the activated output");
+    PK_REQUIRE(!relu || y_act || relu_mask, "pk_bn_bwd: relu needs the activated output or its bit mask");
     PK_REQUIRE(rows > 0 && C > 0 && (C & 7) == 0, "pk_bn_bwd: bad sizes");
     PK_SUPPORTED(C <= BNR_MAXC && C / 8 <= 256, "pk_bn_bwd: C=%d too large", C);
     const size_t chunks = (size_t)rows * (C / 8);
@@ -589,7 +637,7 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     const int nb = pk_bn_bwd_blocks(rows);
     const int rpb = (int)((rows + nb - 1) / nb);
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(nb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw, save_mean,
-                       save_rstd, partial, rows, C, relu, rpb);
+                       save_rstd, partial, rows, C, relu, rpb, relu_mask);
     if (bn_bwd_small(rows)) {          // the reduction of the partial sums rides in the apply launch
         const int ncg = (C + BNS_CG - 1) / BNS_CG;
         int nrb = (int)((rows + 127) / 128);
@@ -599,7 +647,7 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
         const int rpb2 = (int)((rows + nrb - 1) / nrb);
         hipLaunchKernelGGL(k_bn_bwd_apply_fin, dim3(ncg, nrb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw, save_mean,
                            save_rstd, gamma, partial, nb, eval_mode ? 0.f : 1.f / (float)rows, dbeta, dgamma, (uint4*)dx, (uint4*)dresidual, (int)rows,
-                           rpb2, C, relu);
+                           rpb2, C, relu, relu_mask);
         return pk_launch_status("pk_bn_bwd");
     }
     // sums = [sum g | sum g*xhat] for the apply kernel; the same values go to dbeta / dgamma (possibly flat-gradient views)
@@ -607,7 +655,7 @@ extern "C" int pk_bn_bwd(const void* dy, const void* y_act, const void* raw, con
     size_t gb = (chunks + 255) / 256;
     if (gb > 4096) gb = 4096;
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3((unsigned)gb), dim3(256), 0, st, (const uint4*)dy, (const uint4*)y_act, (const uint4*)raw,
-                       save_mean, save_rstd, gamma, sums, eval_mode ? 0.f : 1.f / (float)rows, (uint4*)dx, (uint4*)dresidual, chunks, C / 8, relu);
+                       save_mean, save_rstd, gamma, sums, eval_mode ? 0.f : 1.f / (float)rows, (uint4*)dx, (uint4*)dresidual, chunks, C / 8, relu, relu_mask);
     return pk_launch_status("pk_bn_bwd");
 }
 

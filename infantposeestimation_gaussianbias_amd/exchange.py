@@ -31,10 +31,11 @@ CONV_DT = np.dtype([("x", _P), ("w", _P), ("out", _P), ("stats", _P), ("col_scal
                     ("B", "<i4"), ("Hs", "<i4"), ("Ws", "<i4"), ("Cin", "<i4"), ("Cout", "<i4"), ("ksize", "<i4"), ("stride", "<i4"),
                     ("dilated_input", "<i4"), ("Ho", "<i4"), ("Wo", "<i4"), ("act", "<i4")], align=True)
 BNF_DT = np.dtype([("raw", _P), ("stats_partial", _P), ("gamma", _P), ("beta", _P), ("running_mean", _P), ("running_var", _P),
-                   ("num_batches_tracked", _P), ("residual", _P), ("y", _P), ("save_mean", _P), ("save_rstd", _P), ("rows", "<i8"),
+                   ("num_batches_tracked", _P), ("residual", _P), ("y", _P), ("save_mean", _P), ("save_rstd", _P), ("relu_mask", _P), ("rows", "<i8"),
                    ("tiles", "<i4"), ("C", "<i4"), ("momentum", "<f4"), ("eps", "<f4"), ("relu", "<i4")], align=True)
 BNB_DT = np.dtype([("dy", _P), ("y_act", _P), ("raw", _P), ("save_mean", _P), ("save_rstd", _P), ("gamma", _P), ("partial", _P),
-                   ("dgamma", _P), ("dbeta", _P), ("dx", _P), ("dresidual", _P), ("rows", "<i8"), ("C", "<i4"), ("relu", "<i4")], align=True)
+                   ("dgamma", _P), ("dbeta", _P), ("dx", _P), ("dresidual", _P), ("relu_mask", _P), ("rows", "<i8"), ("C", "<i4"), ("relu", "<i4")],
+                  align=True)
 FUSE_DT = np.dtype([("inputs", _P, (4,)), ("in_h", "<i4", (4,)), ("in_w", "<i4", (4,)), ("n_inputs", "<i4"), ("out", _P), ("mask_y", _P),
                     ("B", "<i4"), ("H", "<i4"), ("W", "<i4"), ("C", "<i4"), ("relu", "<i4")], align=True)
 UPB_DT = np.dtype([("dy", _P), ("mask_y", _P), ("dsrc", _P), ("B", "<i4"), ("H", "<i4"), ("W", "<i4"), ("Hs", "<i4"), ("Ws", "<i4"),
@@ -116,7 +117,8 @@ class _Unit(torch.autograd.Function):
         xs = [t.contiguous() for t in tensors[:n]]
         wc = nnops._wc()
         dev = xs[0].device
-        raws, ys, means, rstds = [None] * len(L), [None] * len(L), [None] * len(L), [None] * len(L)
+        raws, ys, means, rstds, masks = [None] * len(L), [None] * len(L), [None] * len(L), [None] * len(L), [None] * len(L)
+        want_grad = training and any(t.requires_grad for t in tensors)
         for lv in range(plan.n_levels):
             idx = [k for k, l in enumerate(L) if l.level == lv]
             convs, bns = [], []
@@ -133,12 +135,14 @@ class _Unit(torch.autograd.Function):
                     part = nnops._e((tiles, 2, Cout), F32, dev)
                     means[k], rstds[k] = nnops._e((Cout,), F32, dev), nnops._e((Cout,), F32, dev)
                     d.update(out=_p(raws[k]), stats=_p(part))
+                    if l.relu and want_grad and nnops.relu_bitmask():       # the chain step's own ReLU as a bit mask for its BatchNorm backward
+                        masks[k] = nnops._e((M * Cout // 8,), torch.uint8, dev)
                     bn = l.bn
                     wc.bn_eval.pop(id(bn), None)        # the kernel rewrites the running statistics in place (no version bump)
                     bns.append(dict(raw=_p(raws[k]), stats_partial=_p(part), gamma=_p(bn.weight), beta=_p(bn.bias), running_mean=_p(bn.running_mean),
                                     running_var=_p(bn.running_var), num_batches_tracked=_p(bn.num_batches_tracked), y=_p(ys[k]),
-                                    save_mean=_p(means[k]), save_rstd=_p(rstds[k]), rows=M, tiles=tiles, C=Cout, momentum=0.1, eps=1e-5,
-                                    relu=1 if l.relu else 0))
+                                    save_mean=_p(means[k]), save_rstd=_p(rstds[k]), relu_mask=_p(masks[k]), rows=M, tiles=tiles, C=Cout, momentum=0.1,
+                                    eps=1e-5, relu=1 if l.relu else 0))
                 else:                                   # eval without autograd: BatchNorm is an affine map in the conv's epilogue
                     scale, shift = nnops._bn_eval_affine(wc, l.bn, l.bn.weight, l.bn.bias)[:2]
                     ys[k] = nnops._e((B, Ho, Wo, Cout), BF16, dev)
@@ -164,11 +168,11 @@ class _Unit(torch.autograd.Function):
             fuse_rows.append(dict(inputs=[_p(t) for t in terms] + [0] * (4 - len(terms)), in_h=[t.shape[1] for t in terms] + [0] * (4 - len(terms)),
                                   in_w=[t.shape[2] for t in terms] + [0] * (4 - len(terms)), n_inputs=len(terms), out=_p(out), B=Bq, H=H, W=W, C=C, relu=1))
         _launch("pk_fuse_sum_group", FUSE_DT, fuse_rows)
-        if training and any(t.requires_grad for t in tensors):
+        if want_grad:
             ctx.plan = plan
             ctx.n_saved = (len(xs), len(L))
             wds = [wc.dgrad[id(l.conv.weight)] for l in L]
-            ctx.save_for_backward(*xs, *raws, *ys, *means, *rstds, *outs, *wds)
+            ctx.save_for_backward(*xs, *raws, *ys, *means, *rstds, *outs, *wds, *masks)
             ctx.params = tensors[n:]
         return tuple(outs)
 
@@ -180,7 +184,8 @@ class _Unit(torch.autograd.Function):
         sv = ctx.saved_tensors
         xs, raws, ys, means, rstds = sv[:n], sv[n:n + nl], sv[n + nl:n + 2 * nl], sv[n + 2 * nl:n + 3 * nl], sv[n + 3 * nl:n + 4 * nl]
         outs = sv[n + 4 * nl:n + 4 * nl + len(plan.outs)]
-        wds = sv[n + 4 * nl + len(plan.outs):]
+        wds = sv[n + 4 * nl + len(plan.outs):n + 5 * nl + len(plan.outs)]
+        masks = sv[n + 5 * nl + len(plan.outs):]
         params = ctx.params
         dev = xs[0].device
         dout = {i: douts[q].contiguous() for q, i in enumerate(plan.outs)}
@@ -218,8 +223,10 @@ class _Unit(torch.autograd.Function):
                 part = nnops._e((nb, 2, Cout), F32, dev)
                 draws[k] = nnops._e(tuple(raws[k].shape), BF16, dev)
                 keep.append(part)
-                bn_rows.append(dict(dy=_p(dy), y_act=_p(mask), raw=_p(raws[k]), save_mean=_p(means[k]), save_rstd=_p(rstds[k]), gamma=_p(g_p),
-                                    partial=_p(part), dgamma=_p(dgamma), dbeta=_p(dbeta), dx=_p(draws[k]), rows=M, C=Cout, relu=1 if mask is not None else 0))
+                bits = masks[k] if (mask is not None and mask is ys[k]) else None      # the step's own ReLU: its bit mask instead of y
+                bn_rows.append(dict(dy=_p(dy), y_act=0 if bits is not None else _p(mask), raw=_p(raws[k]), save_mean=_p(means[k]),
+                                    save_rstd=_p(rstds[k]), gamma=_p(g_p), partial=_p(part), dgamma=_p(dgamma), dbeta=_p(dbeta), dx=_p(draws[k]),
+                                    relu_mask=_p(bits), rows=M, C=Cout, relu=1 if mask is not None else 0))
             _launch("pk_bn_bwd_group", BNB_DT, bn_rows)
             plain, dil, wg1, wg3, single = [], [], [], [], []
             for k in idx:

@@ -413,6 +413,11 @@ class SkipGrad:
         self.g = None
 
 
+def relu_bitmask() -> bool:
+    """POSE_RELU_BITMASK=0: BatchNorm backward takes its ReLU mask from the activated output again (A/B switch of the round-4 bit masks)."""
+    return os.environ.get("POSE_RELU_BITMASK", "1") != "0"
+
+
 def _bn_eval_affine(wc, bn, gamma, beta):
     """-> (scale, shift, mean, rstd) of an eval-mode BatchNorm: constants of the parameters and the running statistics, computed once
     (4 small ATen launches) and kept in the weight cache until one of them changes."""
@@ -451,17 +456,20 @@ class _ConvBnAct(torch.autograd.Function):
         scale, shift = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
         mean, rstd = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
         y = _e(raw.shape, BF16, dev)
+        # ReLU mask as one bit per element (a byte per 16-byte chunk): BatchNorm backward reads it instead of y (1/16 of the bytes)
+        mask = _e((M * Cout // 8,), torch.uint8, dev) if (relu and not infer and relu_bitmask()) else None
         if training:
             wc.bn_eval.pop(id(bn), None)        # the kernel below rewrites the running statistics in place (no version bump)
             # finalize + apply: one fused launch for small tensors, two kernels otherwise (the library decides)
             call("pk_bn_train_fwd", raw, part, part.shape[0], Cout, M, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked,
-                 0.1, 1e-5, res, y, mean, rstd, scale, shift, 1 if relu else 0, stream_ptr())
+                 0.1, 1e-5, res, y, mean, rstd, scale, shift, 1 if relu else 0, mask, stream_ptr())
         else:
             # eval: scale / shift are constants of the parameters -- computed once (4 small ATen launches) and kept until the weights or
             # the statistics change (was: 4 launches per BatchNorm layer and forward, 320 per HRFormer-base inference step)
             scale, shift, mean, rstd = _bn_eval_affine(wc, bn, gamma, beta)
-            call("pk_bn_act", raw, scale, shift, res, y, M, Cout, 1 if relu else 0, stream_ptr())
-        ctx.save_for_backward(x, raw, y, mean, rstd, gamma, wd)
+            call("pk_bn_act", raw, scale, shift, res, y, M, Cout, 1 if relu else 0, mask, stream_ptr())
+        ctx.save_for_backward(x, raw, y if mask is None else mask, mean, rstd, gamma, wd)
+        ctx.has_mask = mask is not None
         ctx.meta = (stride, relu, training, residual is not None, Cin_real, ksize, (B, Hs, Ws, Ho, Wo))
         return y
 
@@ -478,8 +486,8 @@ class _ConvBnAct(torch.autograd.Function):
         draw = _e(raw.shape, BF16, dev)
         dres = _e(raw.shape, BF16, dev) if has_res else None
         # (eval mode, bit 1: the running statistics are constants, the input gradient is gamma * rstd * g without the batch-mean terms)
-        call("pk_bn_bwd", dy, y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, dres, M, Cout, (1 if relu else 0) | (0 if training else 2),
-             stream_ptr())
+        call("pk_bn_bwd", dy, None if ctx.has_mask else y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, dres, M, Cout,
+             (1 if relu else 0) | (0 if training else 2), y if ctx.has_mask else None, stream_ptr())
         addend = None
         if ctx.skip_in is not None:
             addend, ctx.skip_in.g = ctx.skip_in.g, None
@@ -607,10 +615,10 @@ class _BnActOnly(torch.autograd.Function):
             _wc().bn_eval.pop(id(bn), None)
             scale, shift, mean, rstd = (_e((C,), F32, dev) for _ in range(4))
             call("pk_bn_train_fwd", raw, part, part.shape[0], C, M, gamma, beta, bn.running_mean, bn.running_var, bn.num_batches_tracked, 0.1, 1e-5,
-                 None, y, mean, rstd, scale, shift, 1 if relu else 0, stream_ptr())
+                 None, y, mean, rstd, scale, shift, 1 if relu else 0, None, stream_ptr())
         else:
             scale, shift, mean, rstd = _bn_eval_affine(_wc(), bn, gamma, beta)
-            call("pk_bn_act", raw, scale, shift, None, y, M, C, 1 if relu else 0, stream_ptr())
+            call("pk_bn_act", raw, scale, shift, None, y, M, C, 1 if relu else 0, None, stream_ptr())
         ctx.save_for_backward(raw, y, mean, rstd, gamma)
         ctx.meta = (relu, training, M, C)
         return y
@@ -626,7 +634,7 @@ class _BnActOnly(torch.autograd.Function):
         part, sums = _e((nb, 2, C), F32, dev), _e((2 * C,), F32, dev)
         draw = _e(tuple(raw.shape), BF16, dev)
         call("pk_bn_bwd", dy.contiguous(), y, raw, mean, rstd, gamma, part, sums, dgamma, dbeta, draw, None, M, C, (1 if relu else 0) | (0 if training else 2),
-             stream_ptr())
+             None, stream_ptr())
         return draw, None, None if sg else dgamma, None if sb else dbeta, None, None, None
 
 

@@ -121,7 +121,7 @@ def elementwise_cases(flt):
         x = torch.randn(M, C, device=DEV).to(BF)
         y = torch.empty_like(x)
         sc, sh = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
-        sec = timeit(lambda: call("pk_bn_act", x, sc, sh, None, y, M, C, 1, stream_ptr()))
+        sec = timeit(lambda: call("pk_bn_act", x, sc, sh, None, y, M, C, 1, None, stream_ptr()))
         report(name, sec, None, 2 * M * C * 2)
     for Cc in (32, 256):
         name = f"layernorm fwd 196608x{Cc}"

@@ -1442,8 +1442,9 @@ def test_hrformer_base_twin_expected_gradient_vs_bf16_aware_oracle(golden):
 
 
 def test_hrnet_w18_twin_expected_gradient_vs_bf16_aware_oracle(golden):
-    """The same for HRNet-W18 + heatmap head (C = 18 -> 24 ...), BASELINE cfg 1's model, 128x96, 16 runs per side."""
-    _expected_gradient(golden, "hrnet_w18", 17, "heatmap", "hrnet_w18_heatmap", 41, (96, 128), (24, 32), 16, 800)
+    """The same for HRNet-W18 + heatmap head (C = 18 -> 24 ...), BASELINE cfg 1's model, 128x96, 32 runs per side (0.5 s per oracle run; at 16
+    runs one BatchNorm scale of a three-step down chain sat at 5.4 % against 2 x 2.4 % of its own noise)."""
+    _expected_gradient(golden, "hrnet_w18", 17, "heatmap", "hrnet_w18_heatmap", 41, (96, 128), (24, 32), 32, 800)
 
 
 def test_cfg5_full_size_flip_inference_graph_replay_matches_two_pass_eager(golden, monkeypatch, tmp_path):

@@ -2,6 +2,10 @@
 # round 4, call c: full -m gpu suite, then kernel trace + summary of the default bench, then cfg 4 / cfg 5 quick lines
 set -o pipefail
 mkdir -p gpurun_out
+# heartbeat: long CPU-oracle tests write nothing for minutes; gpurun kills a run that is silent for 7 minutes
+( while true; do sleep 60; echo "[heartbeat $(date +%H:%M:%S)]"; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 1000 python -m pytest tests -m gpu -q -s --timeout 600 -x > gpurun_out/r04c_tests.log 2>&1; rc=$?
 grep -E "expected-gradient|resident|passed|failed|FAILED|^E  " gpurun_out/r04c_tests.log | cut -c1-800 | tail -30

@@ -2,6 +2,10 @@
 # round 4, call e: quick tests of the changed paths, sections profile (serialised branches), bench A/B of small switches
 set -o pipefail
 mkdir -p gpurun_out
+# heartbeat: long CPU-oracle tests write nothing for minutes; gpurun kills a run that is silent for 7 minutes
+( while true; do sleep 60; echo "[heartbeat $(date +%H:%M:%S)]"; done ) &
+HB=$!
+trap "kill $HB 2>/dev/null" EXIT
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout -k 10 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_public_surface.py tests/test_gpu_network_ops.py -m gpu -q -x --timeout 500 \
    -k "fusion_loss or term_methods or constraint or trainer or graph_replay or grouped or head_out or train_step_vs_golden or flip_inference or deferred" > gpurun_out/r04e_tests.log 2>&1; rc=$?

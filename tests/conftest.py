@@ -16,6 +16,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The CPU oracle (PyTorch-CPU) must not oversubscribe: a GPU box gives one job a 16-CPU share of a much larger host, and torch
+    would start one thread per HOST core (the twin expected-gradient tests took 10 minutes that way instead of one)."""
+    import torch
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(16, n)))
+
+
 def pytest_collection_modifyitems(config, items):
     """`-m gpu` tests need a device; skip them (never silently pass) when there is none."""
     import torch

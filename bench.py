@@ -602,6 +602,9 @@ def main():
             line["comm"] = comm_check
         print(json.dumps(line))
     if world > 1:
+        # rank 0 spends seconds on the roofline probes after the timed region: the other ranks wait here instead of tearing the
+        # communicator down under it
+        dist.barrier()
         dist.destroy_process_group()
 
 

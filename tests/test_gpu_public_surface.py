@@ -137,10 +137,11 @@ def test_drop_path_semantics():
     y = m.train()(x)
     torch.manual_seed(3)
     mask = torch.floor(0.75 + torch.rand(64, dtype=torch.float32, device=DEV))
-    ref = (x.detach() / 0.75) * mask.view(64, 1, 1, 1)          # hrformer.py:19-23, same arithmetic order
-    assert torch.equal(y.detach(), ref) and 0 < int(mask.sum()) < 64
+    # hrformer.py:19-23, same arithmetic order: IEEE division, then the mask (numpy: torch's device kernel multiplies by 1 / keep instead)
+    mk = C(mask).reshape(64, 1, 1, 1)
+    assert np.array_equal(C(y), (C(x) / np.float32(0.75)) * mk) and 0 < int(mask.sum()) < 64
     y.backward(torch.ones_like(y))
-    assert torch.equal(x.grad, (torch.ones_like(x) / 0.75) * mask.view(64, 1, 1, 1))
+    assert np.array_equal(C(x.grad), (np.ones_like(C(x)) / np.float32(0.75)) * mk)
 
 
 def test_hrnet_w48_eval_vs_golden(golden):

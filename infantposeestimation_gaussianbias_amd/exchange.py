@@ -135,7 +135,7 @@ class _Unit(torch.autograd.Function):
                     part = nnops._e((tiles, 2, Cout), F32, dev)
                     means[k], rstds[k] = nnops._e((Cout,), F32, dev), nnops._e((Cout,), F32, dev)
                     d.update(out=_p(raws[k]), stats=_p(part))
-                    if l.relu and want_grad and nnops.relu_bitmask():       # the chain step's own ReLU as a bit mask for its BatchNorm backward
+                    if l.relu and want_grad:       # the chain step's own ReLU as a bit mask for its BatchNorm backward
                         masks[k] = nnops._e((M * Cout // 8,), torch.uint8, dev)
                     bn = l.bn
                     wc.bn_eval.pop(id(bn), None)        # the kernel rewrites the running statistics in place (no version bump)

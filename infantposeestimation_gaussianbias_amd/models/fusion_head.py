@@ -5,7 +5,6 @@ Everything numerical runs in libposekernels: `decode` is one kernel per batch (n
 `FusionPoseLoss` is a fused forward (3 launches) + a hand-derived backward (1 launch).
 """
 import math
-import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -108,11 +107,9 @@ class HeatmapRegressionHead(nn.Module):
 
         # the three branches are independent: on concurrent streams their small BatchNorm kernels (finalize, partial sums: a
         # handful of workgroups each) hide under another branch's convolution instead of leaving the GPU idle
-        fns = [make(self.heatmap_branch), make(self.offset_branch), make(self.variance_branch, True)]
-        if os.environ.get("POSE_HEAD_SERIAL", "0") == "1":
-            heatmaps, offsets, variances = [fn([f]) for fn in fns]
-        else:
-            heatmaps, offsets, variances = nnops.parallel(fns, [[f], [f], [f]])
+        # (measured in round 4: the three branches one after the other on one stream cost 0.35 ms per step -- DESIGN.md section 4)
+        heatmaps, offsets, variances = nnops.parallel([make(self.heatmap_branch), make(self.offset_branch), make(self.variance_branch, True)],
+                                                      [[f], [f], [f]])
         B, _, H, W = offsets.shape
         return {"heatmaps": heatmaps, "offsets": offsets.view(B, self.num_keypoints, 2, H, W),
                 "variances": variances, "fusion_weight": torch.sigmoid(self.fusion_weight)}

@@ -413,11 +413,6 @@ class SkipGrad:
         self.g = None
 
 
-def relu_bitmask() -> bool:
-    """POSE_RELU_BITMASK=0: BatchNorm backward takes its ReLU mask from the activated output again (A/B switch of the round-4 bit masks)."""
-    return os.environ.get("POSE_RELU_BITMASK", "1") != "0"
-
-
 def _bn_eval_affine(wc, bn, gamma, beta):
     """-> (scale, shift, mean, rstd) of an eval-mode BatchNorm: constants of the parameters and the running statistics, computed once
     (4 small ATen launches) and kept in the weight cache until one of them changes."""
@@ -457,7 +452,7 @@ class _ConvBnAct(torch.autograd.Function):
         mean, rstd = _e((Cout,), F32, dev), _e((Cout,), F32, dev)
         y = _e(raw.shape, BF16, dev)
         # ReLU mask as one bit per element (a byte per 16-byte chunk): BatchNorm backward reads it instead of y (1/16 of the bytes)
-        mask = _e((M * Cout // 8,), torch.uint8, dev) if (relu and not infer and relu_bitmask()) else None
+        mask = _e((M * Cout // 8,), torch.uint8, dev) if (relu and not infer) else None
         if training:
             wc.bn_eval.pop(id(bn), None)        # the kernel below rewrites the running statistics in place (no version bump)
             # finalize + apply: one fused launch for small tensors, two kernels otherwise (the library decides)
@@ -1267,7 +1262,7 @@ def exchange(xs, fuse, training, n_out=None, first_only=False):
                 dispatch.run_detached(lambda: xg.unit(det, fuse, training, outs=range(1, n)), det)
             return y0
         return xg.unit(xs, fuse, training, outs=range(n if n_out is None else n_out))
-    if first_only and n > 1 and os.environ.get("POSE_LAST_EXCHANGE_DETACHED", "1") != "0":
+    if first_only and n > 1:
         # Last module of the network: only output 0 is consumed (hrformer.py:776 / hrnet.py:441).  The reference still computes outputs
         # 1..n-1; their only lasting effect is the running-statistics update of their BatchNorm layers in training mode.  They leave the
         # critical path: eval mode skips them, training runs them without autograd on a detached side stream that is joined when the

@@ -172,6 +172,7 @@ def _dp_worker(rank, world, port, q, overlap):
     opt = engine.FlatAdamW(model)
     comm = engine.GradientExchange(opt, bucket_mb=0.0001, overlap=overlap)  # ~26 elements per bucket -> several buckets
     comm.broadcast_initial_state()
+    comm.record_exposed = True                          # exposed-communication timing is event-based: a CPU exchange records nothing
     g = torch.Generator().manual_seed(123)
     data = torch.randn(8, 6, generator=g)
     shard = data[rank * 4:(rank + 1) * 4]
@@ -182,6 +183,7 @@ def _dp_worker(rank, world, port, q, overlap):
         (y ** 2).sum().backward()
         comm.finish()
         grads.append(opt.grad.clone())
+    assert comm.exposed_ms() is None
     # numpy arrays are pickled by value (tensors travel as file descriptors that die with the exiting worker: flaky)
     q.put((rank, opt.flat.detach().numpy().copy(), [g.numpy().copy() for g in grads], len(comm.buckets), list(opt.active)))
     dist.barrier()

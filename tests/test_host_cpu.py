@@ -292,3 +292,22 @@ def test_deconv_parity_class_decomposition_is_conv_transpose(k):
     assert want.shape == got.shape and torch.allclose(got, want, atol=1e-12)
     with pytest.raises(ValueError):
         nnops._deconv_taps(3)
+
+
+def test_bench_profile_fields_carry_their_source_and_go_stale(tmp_path, monkeypatch):
+    """the in-step fields bench.py reads from profiles/ name their source files and the fingerprint of the code they were
+    captured with; a profile taken with other kernel sources / launch logic is reported stale (bench.py then drops those fields)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    prof, steps = bench.load_step_profile()
+    assert steps >= 4 and any(k.startswith("k_conv8p") for k in prof)
+    lps, us, union_ms = prof["k_conv8p(IgemmArgs)"]
+    assert lps == 7 and us > 100 and union_ms is not None and union_ms * 1e3 < lps * us       # concurrent launches: union < sum
+    src = bench.profile_source()
+    assert src["files"][0].startswith("profiles/") and src["captured_at_code_sha16"] and src["current_code_sha16"]
+    fake = tmp_path / "meta.json"
+    fake.write_text('{"code_sha16": "0000000000000000", "command": "x"}')
+    monkeypatch.setattr(bench, "PROFILE_META", str(fake))
+    assert bench.profile_source()["stale"] is True
+    e = bench._entry("k", "shape", "mfma", 1e-4, flops=1e9, trace="k_conv8p(IgemmArgs)", single_shape=True, prof=prof, pmc=({}, {}))
+    assert e["frac_in_step_union"] > e["frac_in_step"] > 0

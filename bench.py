@@ -58,8 +58,11 @@ def time_kernel(fn, iters=20, warmup=3):
     try:
         g, side = torch.cuda.CUDAGraph(), torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
+        # N > 1: the process group's watchdog thread may query events while we capture; only police the capturing thread's own calls
+        # (as engine.Trainer._capture does); all collectives have completed by the time the probes run
+        mode = "thread_local" if (dist.is_initialized() and dist.get_world_size() > 1) else "global"
         with torch.cuda.stream(side):
-            with torch.cuda.graph(g, stream=side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode=mode):
                 for _ in range(iters):
                     fn()
         torch.cuda.current_stream().wait_stream(side)
@@ -570,9 +573,15 @@ def main():
         log(f"timed region: {dt:.3f} s for {args.steps} steps -> {B * world * args.steps / dt:.1f} img/s")
         roof = None
         if not args.no_roofline:
-            table = roofline_table(model, B, trainer) if args.config == "hrformer_small" else roofline_other(args.config, model, B, c)
-            roof = dict(table[0])
-            roof["table"] = table
+            try:
+                if world > 1:
+                    time.sleep(0.5)          # one watchdog polling period: the timed region's collectives are retired
+                table = roofline_table(model, B, trainer) if args.config == "hrformer_small" else roofline_other(args.config, model, B, c)
+                roof = dict(table[0])
+                roof["table"] = table
+            except Exception as e:       # noqa: BLE001  (the probes must never cost the measurement: the line is printed regardless)
+                log(f"roofline probes failed ({type(e).__name__}: {e}); reporting the timed region without them")
+                table = []
             for e in table:
                 log(f"roofline: {e['kernel'][:48]:48s} {e['us_per_launch']:8.1f} us isolated ({e.get('us_in_step_avg', '-')} in step)  "
                     f"{e['achieved']:8.1f} {e['unit']} = {e['frac'] * 100:5.1f} % of {e['bound']} peak")

@@ -211,7 +211,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
     uint16_t *sQ = sTiles, *sK = sTiles + 64 * RP, *sdO = sTiles + 2 * 64 * RP;
     const int lane0 = threadIdx.x;
     const int h = blockIdx.x % heads;
-    for (int i = lane0; i < 169; i += 64) sBias[i] = table[i * heads + h];
+    // Score arithmetic (as in pk_block.hip's k_attn_bwd): the bias table is kept in units of log2 and the score / dP accumulators START
+    // at -lse / scale and -delta, so P = exp2(fma(acc, scale * log2 e, bias')) and dS = P * acc'; validity comes from the TILE index
+    // (tiles 0..2 hold only real tokens, tile 3 the single token 48), so selects and clamps exist only on the edge tiles.
+    constexpr float LOG2E = 1.44269504088896340736f;
+    const float scale2 = scale * LOG2E, inv_scale = 1.f / scale;
+    for (int i = lane0; i < 169; i += 64) sBias[i] = table[i * heads + h] * LOG2E;
     int a4[4][4];                       // A(t) of the 16 tokens t = 16c + 4g4 + r this lane owns along accumulator rows (-1: padding)
 #pragma unroll
     for (int c = 0; c < 4; ++c)
@@ -261,8 +266,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
                     de += __uint_as_float(orow[c][q] << 16) * __uint_as_float(grow[c][q] << 16);
                     de += __uint_as_float(orow[c][q] & 0xffff0000u) * __uint_as_float(grow[c][q] & 0xffff0000u);
                 }
-            sLse[lane0] = l;
-            sDelta[lane0] = de;
+            sLse[lane0] = -l * inv_scale;
+            sDelta[lane0] = -de;
         }
         __syncthreads();
         uint16_t* dq = dqkv + (size_t)w * AT_N * 3 * C + h * d;
@@ -277,9 +282,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
 #pragma unroll
         for (int ci = 0; ci < 4; ++ci) {
             const int i = 16 * ci + l16;
-            const bool iok = i < AT_N;
+            const bool iok = ci < 3 || l16 == 0;
             const int ai = rel_a(iok ? i : 0) + 84 + lz;
             const float li = sLse[i], di = sDelta[i];
+            const f32x4 li4 = {li, li, li, li}, di4 = {di, di, di, di};
             bf16x8 qfi[DK], ofi[DK];
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) {
@@ -295,7 +301,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int cj = 2 * s + u;
-                    f32x4 sc = zero, dp = zero;
+                    f32x4 sc = li4, dp = di4;
 #pragma unroll
                     for (int ks = 0; ks < DK; ++ks) {
                         sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sK, 16 * cj + l16, RP, 32 * ks + g4 * 8), qfi[ks], sc, 0, 0, 0);
@@ -303,9 +309,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float ev = __expf(sc[r] * scale + sBias[ai - (a4[cj][r] >= 0 ? a4[cj][r] : 0)] - li);
-                        const float pv = (iok && a4[cj][r] >= 0) ? ev : 0.f;      // select after the fact: straight-line code
-                        ds[u][r] = pv * (dp[r] - di);
+                        const bool jv = cj < 3 || (g4 == 0 && r == 0);
+                        const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], scale2, sBias[ai - (cj < 3 ? a4[cj][r] : max(a4[cj][r], 0))]));
+                        const float pv = (iok && jv) ? ev : 0.f;      // select after the fact: straight-line code
+                        ds[u][r] = pv * dp[r];
                         dsum[ci][cj][r] += ds[u][r];
                     }
                 }
@@ -325,7 +332,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
 #pragma unroll
         for (int cj = 0; cj < 4; ++cj) {
             const int j = 16 * cj + l16;
-            const bool jok = j < AT_N;
+            const bool jok = cj < 3 || l16 == 0;
             const int ajn = 84 - rel_a(jok ? j : 0) + lz;
             bf16x8 kfj[DK];
 #pragma unroll
@@ -339,20 +346,20 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int ci = 2 * s + u;
-                    f32x4 sc = zero, dp = zero;
+                    f32x4 sc = *reinterpret_cast<const f32x4*>(&sLse[16 * ci + 4 * g4]);
+                    f32x4 dp = *reinterpret_cast<const f32x4*>(&sDelta[16 * ci + 4 * g4]);
 #pragma unroll
                     for (int ks = 0; ks < DK; ++ks) {
                         sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sQ, 16 * ci + l16, RP, 32 * ks + g4 * 8), kfj[ks], sc, 0, 0, 0);
                         dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sdO, 16 * ci + l16, RP, 32 * ks + g4 * 8), vf[cj][ks], dp, 0, 0, 0);
                     }
-                    const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sLse[16 * ci + 4 * g4]);
-                    const f32x4 de4 = *reinterpret_cast<const f32x4*>(&sDelta[16 * ci + 4 * g4]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float ev = __expf(sc[r] * scale + sBias[(a4[ci][r] >= 0 ? a4[ci][r] : 0) + ajn] - l4[r]);
-                        const float pv = (jok && a4[ci][r] >= 0) ? ev : 0.f;
+                        const bool iv = ci < 3 || (g4 == 0 && r == 0);
+                        const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], scale2, sBias[(ci < 3 ? a4[ci][r] : max(a4[ci][r], 0)) + ajn]));
+                        const float pv = (jok && iv) ? ev : 0.f;
                         pp[u][r] = pv;
-                        ds[u][r] = pv * (dp[r] - de4[r]);
+                        ds[u][r] = pv * dp[r];
                     }
                 }
                 const bf16x8 pf = pack_frag(pp[0], pp[1], 1.f), df = pack_frag(ds[0], ds[1], 1.f);
@@ -375,7 +382,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
     // Fold the register-resident [49][49] bias gradient onto the 169 table entries inside the workgroup (fixed summation
     // order -> deterministic): the partial result per workgroup is 169 floats instead of 2401.
     __syncthreads();
-    float* sD = reinterpret_cast<float*>(sTiles);            // 49*49*4 = 9604 B <= 3*64*RP*2 = 15360 B
+    // (the tile sits 320 floats into the buffer: the fold below also reads -- and masks -- words up to 294 before and 293 after it)
+    static_assert((320 + 6 * 7 * AT_N + 12 * AT_N + AT_N) * 4 <= 3 * 64 * RP * 2, "bias-gradient tile + slack must fit the Q/K/dO tiles");
+    float* sD = reinterpret_cast<float*>(sTiles) + 320;      // 49*49*4 = 9604 B at +1280 B <= 3*64*RP*2 = 15360 B
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
 #pragma unroll
@@ -386,16 +395,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
                 if (i < AT_N && j < AT_N) sD[i * AT_N + j] = dsum[ci][cj][r];
             }
     __syncthreads();
+    // (rows yj in a loop, the seven xj of a row unrolled under bit masks: the wave pays for its longest lane -- 49 trips of a two-level
+    // loop per round before, 5 + 7 + 4 row trips over the three rounds now; the terms are added in the same order)
     for (int e = lane0; e < 169; e += 64) {
         const int dy = e / 13 - 6, dx = e % 13 - 6;
+        const int x0 = max(0, -dx), x1 = min(AT_WS, AT_WS - dx);
+        unsigned keep[AT_WS];
+#pragma unroll
+        for (int xj = 0; xj < AT_WS; ++xj) keep[xj] = (xj >= x0 && xj < x1) ? 0xffffffffu : 0u;
+        const int base = (dy * AT_WS + dx) * AT_N;                       // + yj * (7 * 49 + 7) + xj * (49 + 1)
         float acc = 0.f;
-        for (int yj = 0; yj < AT_WS; ++yj) {
-            const int yi = yj + dy;
-            if (yi < 0 || yi >= AT_WS) continue;
+        for (int yj = max(0, -dy); yj < min(AT_WS, AT_WS - dy); ++yj) {
+#pragma unroll
             for (int xj = 0; xj < AT_WS; ++xj) {
-                const int xi = xj + dx;
-                if (xi < 0 || xi >= AT_WS) continue;
-                acc += sD[(yi * AT_WS + xi) * AT_N + yj * AT_WS + xj];
+                // (an xj outside [x0, x1) addresses some other word of the tile buffer or just outside it: read, masked to +0)
+                const float v = sD[base + yj * (AT_WS * AT_N + AT_WS) + xj * (AT_N + 1)];
+                acc += __uint_as_float(__float_as_uint(v) & keep[xj]);
             }
         }
         dbias_part[(size_t)blockIdx.x * 169 + e] = acc;

@@ -33,6 +33,7 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
 
 #define OOB_OFF 0x80000000u
 #define MAKE_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc(const_cast<uint16_t*>(ptr), 0, 0x7ffffff0, 0x00020000)
+#define LOG2E_F 1.44269504088896340736f
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0)
 #define LO4(v) __builtin_shufflevector(v, v, 0, 1, 2, 3)        // the two 16-deep operands inside a 32-deep one
@@ -1285,7 +1286,9 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
         sBet[i] = p.beta[i];
     }
     if (tid < 64) sA[tid] = tid < AT_N ? rel_a7(tid) : -1;
-    for (int i = tid; i < HEADS * 169; i += 256) sBias[i / 169][i % 169] = p.table[(i % 169) * HEADS + i / 169];
+    // (the bias table is kept in units of log2 and the score / dP accumulators START at -lse / scale and -delta, so
+    // P = exp2(fma(acc, scale * log2 e, bias')) and dS = P * acc': three instructions per score besides the bias gather)
+    for (int i = tid; i < HEADS * 169; i += 256) sBias[i / 169][i % 169] = p.table[(i % 169) * HEADS + i / 169] * LOG2E_F;
     for (int i = tid; i < 4 * HEADS * 192; i += 256) (&sTab[0][0][0])[i] = 0.f;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 dgam[NCT], dbet[NCT];
@@ -1296,12 +1299,18 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
     const auto rg = MAKE_RSRC(p.dy);
     const auto ro = MAKE_RSRC(p.out);
     const auto rs = MAKE_RSRC(p.o_save);
-    const auto rq = MAKE_RSRC(p.dqkv);
-    const float inv_c = 1.f / (float)C, scale = p.softmax_scale;
+    const float inv_c = 1.f / (float)C, scale = p.softmax_scale, scale2 = p.softmax_scale * LOG2E_F, inv_scale = 1.f / p.softmax_scale;
     for (int w = blockIdx.x * 4 + wave; w < p.n_windows; w += gridDim.x * 4) {
         const int lane = opaque_lane<true>(lane_), i16 = lane & 15, g = lane >> 4;
         int row[4];
         float mean[4], rstd[4];
+        // du = dqkv W_qkv, accumulated tile by tile from the packed dq / dk / dv fragments as the passes produce them: the lane that packs
+        // the 8 channels 32 kq + 8g .. of token 16t + i16 for the store is the lane whose B operand they are (no read-back, no transpose)
+        f32x4 du[4][NCT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) du[t][ct] = zero;
         {   // ================= phase 1: the attention core; writes dqkv (and u) rows of this window
             u32x4 xr[4][NK], dyr[4][NK];
 #pragma unroll
@@ -1388,10 +1397,9 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                     for (int r = 0; r < 4; ++r) de += a[3][0][r] * o0[r] + a[3][1][r] * o1[r];
                     de = xor16_sum(de);
                     de = xor32_sum(de);
-                    const float l = lsv[t];
                     if (g == 0) {
-                        sLse[wave][i] = l;
-                        sDelta[wave][i] = de;
+                        sLse[wave][i] = -lsv[t] * inv_scale;
+                        sDelta[wave][i] = -de;
                     }
                 }
                 // ---- e-form operands (lane = head channel hid(ce, i16), slots = the 32 tokens of K-step s in accumulator order): K now,
@@ -1416,10 +1424,13 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                 // ---- pass 1: transposed scores, lane = query i:  dS^T, bias gradient, dQ^T = scale * K^T dS^T
 #pragma unroll
                 for (int ci = 0; ci < 4; ++ci) {
+                    // (validity from the tile index, not from loaded values: tiles 0..2 hold only real tokens, so their selects,
+                    // clamps and predicated stores disappear at compile time; tile 3 has the single real token 48)
                     const int i = 16 * ci + i16;
-                    const bool iok = i < AT_N;
+                    const bool iok = ci < 3 || i16 == 0;
                     const int ai = rel_a7(iok ? i : 0) + 84;
                     const float li = sLse[wave][i], di = sDelta[wave][i];
+                    const f32x4 li4 = {li, li, li, li}, di4 = {di, di, di, di};
                     f32x4 dq[2] = {zero, zero};
 #pragma unroll
                     for (int s = 0; s < 2; ++s) {
@@ -1427,37 +1438,55 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int cj = 2 * s + u;
-                            const f32x4 scr = MFMA(kf[cj], qf[ci], zero), dp = MFMA(vf[cj], dof[ci], zero);
+                            const f32x4 scr = MFMA(kf[cj], qf[ci], li4), dp = MFMA(vf[cj], dof[ci], di4);
                             const int4 aj = *reinterpret_cast<const int4*>(&sA[16 * cj + 4 * g]);
                             const int ajr[4] = {aj.x, aj.y, aj.z, aj.w};
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const int e = ai - (ajr[r] >= 0 ? ajr[r] : 0);
-                                const float ev = __expf(scr[r] * scale + sBias[h][e] - li);
-                                const float pv = (iok && ajr[r] >= 0) ? ev : 0.f;
-                                ds[u][r] = pv * (dp[r] - di);
+                                const bool jv = cj < 3 || (g == 0 && r == 0);
+                                const int e = ai - (cj < 3 ? ajr[r] : max(ajr[r], 0));
+                                const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(scr[r], scale2, sBias[h][e]));
+                                const float pv = (iok && jv) ? ev : 0.f;
+                                ds[u][r] = pv * dp[r];
                                 // d(bias)[i][j] of this window -> wave-private tile, folded onto the 169 table entries after the pass.
                                 // (LDS float atomics straight into the table were measured: ~200 cycles per ds_add_f32 wave-instruction,
                                 // 95 us of a 159 us kernel; 64 accumulator registers per head instead cost a wave of occupancy.)
-                                if (iok && ajr[r] >= 0) sFold[wave][i * AT_N + 16 * cj + 4 * g + r] = ds[u][r];
+                                if (iok && jv) sFold[wave][i * AT_N + 16 * cj + 4 * g + r] = ds[u][r];
                             }
                         }
                         const bf16x8 df = pack2(ds[0], ds[1]);
 #pragma unroll
                         for (int ce = 0; ce < 2; ++ce) dq[ce] = MFMA(Kt[s][ce], df, dq[ce]);
                     }
+                    {       // rows 4g + r of tile ce  <->  head channel 8g + 4ce + r
+                        const u32x2 q0 = pack4(dq[0] * scale), q1 = pack4(dq[1] * scale);
+                        const u32x4 qv = iok ? (u32x4){q0[0], q0[1], q1[0], q1[1]} : (u32x4){0u, 0u, 0u, 0u};
+                        if (iok) *reinterpret_cast<u32x4*>(dq_base + (size_t)i * 3 * C + 32 * h + 8 * g) = qv;
 #pragma unroll
-                    for (int ce = 0; ce < 2; ++ce)      // rows 4g + r of tile ce  <->  head channel 8g + 4ce + r
-                        if (iok) *reinterpret_cast<u32x2*>(dq_base + (size_t)i * 3 * C + 32 * h + 8 * g + 4 * ce) = pack4(dq[ce] * scale);
+                        for (int ct = 0; ct < NCT; ++ct)
+                            du[ci][ct] = MFMA(LDS_FRAG(sWt, ct * NKQ + h, lane), __builtin_bit_cast(bf16x8, qv), du[ci][ct]);
+                    }
                 }
                 {        // fold: table entry e = (dy + 6) * 13 + dx + 6 sums dS[i][j] over the pairs with i - j = (dy, dx)
                     LDS_FENCE();
+                    // (rows yj in a loop, the seven xj of a row unrolled with a select: the wave pays for its longest lane, 49 trips of a
+                    // two-level loop before, 5 + 7 + 4 row trips over the three rounds now; terms in the same order)
                     for (int e = lane; e < 169; e += 64) {
                         const int dy_ = e / 13 - 6, dx_ = e % 13 - 6;
+                        const int x0 = max(0, -dx_), x1 = min(7, 7 - dx_);
+                        const int base = wave * (AT_N * AT_N) + (dy_ * 7 + dx_) * AT_N;        // + yj * 350 + xj * 50
+                        unsigned keep[7];               // (bit masks, not selects: a select lets the compiler sink each load into a branch)
+#pragma unroll
+                        for (int xj = 0; xj < 7; ++xj) keep[xj] = (xj >= x0 && xj < x1) ? 0xffffffffu : 0u;
                         float acc = 0.f;
-                        for (int yj = max(0, -dy_); yj < min(7, 7 - dy_); ++yj)
-                            for (int xj = max(0, -dx_); xj < min(7, 7 - dx_); ++xj)
-                                acc += sFold[wave][((yj + dy_) * 7 + xj + dx_) * AT_N + yj * 7 + xj];
+                        for (int yj = max(0, -dy_); yj < min(7, 7 - dy_); ++yj) {
+#pragma unroll
+                            for (int xj = 0; xj < 7; ++xj) {
+                                // (an xj outside [x0, x1) addresses some other float of the tile array or beyond it: read, masked to +0)
+                                const float v = (&sFold[0][0])[base + yj * (7 * AT_N + 7) + xj * (AT_N + 1)];
+                                acc += __uint_as_float(__float_as_uint(v) & keep[xj]);
+                            }
+                        }
                         sTab[wave][h][e] += acc;
                     }
                     LDS_FENCE();
@@ -1491,7 +1520,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
 #pragma unroll
                 for (int cj = 0; cj < 4; ++cj) {
                     const int j = 16 * cj + i16;
-                    const bool jok = j < AT_N;
+                    const bool jok = cj < 3 || i16 == 0;
                     const int ajn = 84 - rel_a7(jok ? j : 0);
                     f32x4 dv[2] = {zero, zero}, dk[2] = {zero, zero};
 #pragma unroll
@@ -1500,17 +1529,18 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
 #pragma unroll
                         for (int u = 0; u < 2; ++u) {
                             const int ci = 2 * s + u;
-                            const f32x4 scr = MFMA(qf[ci], kf[cj], zero), dp = MFMA(dof[ci], vf[cj], zero);
                             const f32x4 l4 = *reinterpret_cast<const f32x4*>(&sLse[wave][16 * ci + 4 * g]);
                             const f32x4 de4 = *reinterpret_cast<const f32x4*>(&sDelta[wave][16 * ci + 4 * g]);
+                            const f32x4 scr = MFMA(qf[ci], kf[cj], l4), dp = MFMA(dof[ci], vf[cj], de4);
                             const int4 aq = *reinterpret_cast<const int4*>(&sA[16 * ci + 4 * g]);
                             const int aqr[4] = {aq.x, aq.y, aq.z, aq.w};
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                const float ev = __expf(scr[r] * scale + sBias[h][(aqr[r] >= 0 ? aqr[r] : 0) + ajn] - l4[r]);
-                                const float pv = (jok && aqr[r] >= 0) ? ev : 0.f;
+                                const bool iv = ci < 3 || (g == 0 && r == 0);
+                                const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(scr[r], scale2, sBias[h][(ci < 3 ? aqr[r] : max(aqr[r], 0)) + ajn]));
+                                const float pv = (jok && iv) ? ev : 0.f;
                                 pp[u][r] = pv;
-                                ds[u][r] = pv * (dp[r] - de4[r]);
+                                ds[u][r] = pv * dp[r];
                             }
                         }
                         const bf16x8 pf = pack2(pp[0], pp[1]), df = pack2(ds[0], ds[1]);
@@ -1520,57 +1550,55 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                             dk[ce] = MFMA(Qt[s][ce], df, dk[ce]);
                         }
                     }
-#pragma unroll
-                    for (int ce = 0; ce < 2; ++ce)
+                    {
+                        const u32x2 k0 = pack4(dk[0] * scale), k1 = pack4(dk[1] * scale), v0 = pack4(dv[0]), v1 = pack4(dv[1]);
+                        const u32x4 kv = jok ? (u32x4){k0[0], k0[1], k1[0], k1[1]} : (u32x4){0u, 0u, 0u, 0u};
+                        const u32x4 vv = jok ? (u32x4){v0[0], v0[1], v1[0], v1[1]} : (u32x4){0u, 0u, 0u, 0u};
                         if (jok) {
-                            *reinterpret_cast<u32x2*>(dq_base + (size_t)j * 3 * C + C + 32 * h + 8 * g + 4 * ce) = pack4(dk[ce] * scale);
-                            *reinterpret_cast<u32x2*>(dq_base + (size_t)j * 3 * C + 2 * C + 32 * h + 8 * g + 4 * ce) = pack4(dv[ce]);
+                            *reinterpret_cast<u32x4*>(dq_base + (size_t)j * 3 * C + C + 32 * h + 8 * g) = kv;
+                            *reinterpret_cast<u32x4*>(dq_base + (size_t)j * 3 * C + 2 * C + 32 * h + 8 * g) = vv;
                         }
+#pragma unroll
+                        for (int ct = 0; ct < NCT; ++ct) {
+                            du[cj][ct] = MFMA(LDS_FRAG(sWt, ct * NKQ + HEADS + h, lane), __builtin_bit_cast(bf16x8, kv), du[cj][ct]);
+                            du[cj][ct] = MFMA(LDS_FRAG(sWt, ct * NKQ + 2 * HEADS + h, lane), __builtin_bit_cast(bf16x8, vv), du[cj][ct]);
+                        }
+                    }
                 }
                 LDS_FENCE();                // the reads of sLse / sDelta complete before the next head rewrites them
             }
         }
-        // ================= phase 2: du = dqkv W_qkv from the rows this wave has just written (bf16, exactly what the weight-gradient
-        // GEMM will read), LayerNorm backward + residual gradient in accumulator layout, one token tile at a time
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's dqkv stores have completed before it reads them back
+        // ================= phase 2: LayerNorm backward + residual gradient in accumulator layout, one token tile at a time; x and dy
+        // of all four tiles are requested up front (one round trip instead of four)
+        u32x2 xo4[4][NCT], dyo4[4][NCT];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int ct = 0; ct < NCT; ++ct) {
+                const unsigned off = row[t] >= 0 ? (unsigned)row[t] * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF;
+                xo4[t][ct] = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
+                dyo4[t][ct] = __builtin_amdgcn_raw_buffer_load_b64(rg, off, 0, 0);
+            }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int n = 16 * t + i16;
             const int rw = row[t];
             const float mu = mean[t], rsd = rstd[t];
             const bool valid = rw >= 0;
-            const unsigned qb = n < AT_N ? (unsigned)((w * AT_N + n) * 3 * C + 8 * g) * 2u : OOB_OFF;
-            f32x4 du[NCT];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) du[ct] = zero;
-#pragma unroll
-            for (int kq = 0; kq < NKQ; ++kq) {
-                const bf16x8 b = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rq, n < AT_N ? qb + 64 * kq : OOB_OFF, 0, 0));
-#pragma unroll
-                for (int ct = 0; ct < NCT; ++ct) du[ct] = MFMA(LDS_FRAG(sWt, ct * NKQ + kq, lane), b, du[ct]);
-            }
-            u32x2 xo[NCT], dyo[NCT];
-#pragma unroll
-            for (int ct = 0; ct < NCT; ++ct) {
-                const unsigned off = valid ? (unsigned)rw * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF;
-                xo[ct] = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
-                dyo[ct] = __builtin_amdgcn_raw_buffer_load_b64(rg, off, 0, 0);
-            }
             f32x4 xh[NCT], gamA[NCT];
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
                 gamA[ct] = *reinterpret_cast<const f32x4*>(&sGam[16 * ct + 4 * g]);
-                xh[ct] = (unpack4(xo[ct]) - mu) * rsd;
+                xh[ct] = (unpack4(xo4[t][ct]) - mu) * rsd;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float gh = du[ct][r] * gamA[ct][r];
+                    const float gh = du[t][ct][r] * gamA[ct][r];
                     s1 += gh;
                     s2 += gh * xh[ct][r];
                 }
                 if (valid) {            // pad tokens are not LayerNorm outputs: their gradient is dropped (hrformer.py:103-114)
-                    dgam[ct] += du[ct] * xh[ct];
-                    dbet[ct] += du[ct];
+                    dgam[ct] += du[t][ct] * xh[ct];
+                    dbet[ct] += du[t][ct];
                 }
             }
             s1 = xor16_sum(s1);
@@ -1580,7 +1608,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
             const float m1 = s1 * inv_c, m2 = s2 * inv_c;
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                const f32x4 o = (du[ct] * gamA[ct] - m1 - xh[ct] * m2) * rsd + unpack4(dyo[ct]);
+                const f32x4 o = (du[t][ct] * gamA[ct] - m1 - xh[ct] * m2) * rsd + unpack4(dyo4[t][ct]);
                 __builtin_amdgcn_raw_buffer_store_b64(pack4(o), ro, valid ? (unsigned)rw * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF, 0, 0);
             }
         }

@@ -254,13 +254,23 @@ __device__ __forceinline__ float row16_sum(float v) {
 
 
 // Cross-row combines for values laid out as 4 rows x 16 columns per wave (lane = 16 * row + column): the xor-16 / xor-32 butterfly
-// steps with the gfx950 row swaps (v_permlane16_swap / v_permlane32_swap, VALU rate) instead of ds_bpermute_b32.  With both operands
-// the same register, the swap returns (rows 0,0,2,2 | rows 1,1,3,3) resp. (low half twice | high half twice): combining the two
-// results is the butterfly step, same operand pairs as before (bitwise identical sums).
+// steps.  xor 32: the gfx950 half swap v_permlane32_swap (VALU rate; with both operands the same register it returns low half twice |
+// high half twice, and combining the two results is the butterfly step).  xor 16: ds_swizzle_b32 in bit-mask mode (lane ^ 16 inside each
+// 32-lane half: the LDS crossbar, no LDS memory).  It was v_permlane16_swap until round 4: in k_attn_fwd_w the LayerNorm sums taken with
+// it came out different from run to run (a few lanes of a few windows, one bf16 ulp in the output) whenever other kernels shared the chip --
+// only with other streams active, only the 16-row swap, only in the reductions that run while buffer loads are in flight; padding it with
+// wait states or a full s_waitcnt changed nothing, replacing it made 0 of 80 forwards differ instead of 50-60 (scripts/probes/
+// cfg5_locate2.py).  Same operand pairs as before: bitwise the same sums.
+__device__ __forceinline__ float xor16_partner(float v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));       // and 0x1f, or 0, xor 0x10
+#else
+    return v;
+#endif
+}
 __device__ __forceinline__ float xor16_sum(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    return v + xor16_partner(v);
 #else
     return v;
 #endif
@@ -275,8 +285,7 @@ __device__ __forceinline__ float xor32_sum(float v) {
 }
 __device__ __forceinline__ float xor16_max(float v) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return fmaxf(v, xor16_partner(v));
 #else
     return v;
 #endif

@@ -215,10 +215,13 @@ class DeviceCropper:
             off += (im.size + 15) // 16 * 16
         nd = desc.nbytes
         host, slot = self._staging(off + (nd + 15) // 16 * 16)          # [images | descriptor table]: ONE host-to-device copy
+        # plain memcpy through a numpy view: a torch slice assignment fans every 0.9 MB image out over all intra-op threads (128 on the
+        # GPU host: 21 ms per 64 images against 1.4 ms; scripts/probes/cropper_phases.py)
+        hv = host.numpy()
         for i, im in enumerate(sizes):
             o = int(desc[i]["off"])
-            host[o:o + im.size] = torch.from_numpy(np.ascontiguousarray(im).reshape(-1))
-        host[off:off + nd] = torch.from_numpy(desc.view(np.uint8))
+            np.copyto(hv[o:o + im.size], np.ascontiguousarray(im).reshape(-1))
+        np.copyto(hv[off:off + nd], desc.view(np.uint8))
         dev_buf = host.to(self.device, non_blocking=True)
         if slot is not None:
             self._pin_ev[slot] = torch.cuda.Event()

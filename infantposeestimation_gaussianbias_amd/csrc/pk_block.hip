@@ -1266,7 +1266,11 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
     __shared__ float sBias[HEADS][176];
     __shared__ __attribute__((aligned(16))) float sLse[4][64], sDelta[4][64];
     __shared__ float sTab[4][HEADS][192];                                      // rel-pos-bias gradient of this wave: entry e owned by lane e % 64
-    __shared__ float sFold[4][AT_N * AT_N];                                    // dS of the current (window, head), folded onto sTab once per window
+    // dS of the current (window, head), folded onto sTab once per window.  FOLD_PAD floats of slack on both sides: the fold reads (and
+    // masks) words up to 294 before wave 0's tile and 293 after wave 3's -- they stay inside this array whatever the LDS layout is.
+    constexpr int FOLD_PAD = 296;
+    __shared__ float sFoldBuf[FOLD_PAD + 4 * AT_N * AT_N + FOLD_PAD];
+    float* const sFold0 = sFoldBuf + FOLD_PAD;
     __shared__ float sRed[4][2][C];
     const int tid = threadIdx.x, lane_ = tid & 63, wave = tid >> 6;
     stage_frags(sWa, p.wqkv, HEADS * F_A, C,
@@ -1451,7 +1455,7 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                                 // d(bias)[i][j] of this window -> wave-private tile, folded onto the 169 table entries after the pass.
                                 // (LDS float atomics straight into the table were measured: ~200 cycles per ds_add_f32 wave-instruction,
                                 // 95 us of a 159 us kernel; 64 accumulator registers per head instead cost a wave of occupancy.)
-                                if (iok && jv) sFold[wave][i * AT_N + 16 * cj + 4 * g + r] = ds[u][r];
+                                if (iok && jv) sFold0[wave * (AT_N * AT_N) + i * AT_N + 16 * cj + 4 * g + r] = ds[u][r];
                             }
                         }
                         const bf16x8 df = pack2(ds[0], ds[1]);
@@ -1482,8 +1486,8 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                         for (int yj = max(0, -dy_); yj < min(7, 7 - dy_); ++yj) {
 #pragma unroll
                             for (int xj = 0; xj < 7; ++xj) {
-                                // (an xj outside [x0, x1) addresses some other float of the tile array or beyond it: read, masked to +0)
-                                const float v = (&sFold[0][0])[base + yj * (7 * AT_N + 7) + xj * (AT_N + 1)];
+                                // (an xj outside [x0, x1) addresses some other float of the padded tile array: read, masked to +0)
+                                const float v = sFold0[base + yj * (7 * AT_N + 7) + xj * (AT_N + 1)];
                                 acc += __uint_as_float(__float_as_uint(v) & keep[xj]);
                             }
                         }

@@ -167,7 +167,10 @@ def join_detached():
 # >= 2 048-workgroup grids take CUs from the critical chain instead of filling its bubbles, and hipGraph maps parallel branches
 # onto 4 hardware queues (DEBUG_HIP_FORCE_GRAPH_QUEUES; more queues do not help).  Round 3, again for the SERIAL phases only (stem, layer1,
 # transitions: one kernel in flight, the weight gradients of >= 100 000-row convs on one auxiliary stream joined by finalize_deferred):
-# 17.16 vs 17.21 ms over four alternating runs each -- inside the noise, not kept.)
+# 17.16 vs 17.21 ms over four alternating runs each -- inside the noise, not kept.  Round 4, only the slab launches of the LOW-resolution
+# branches (i >= 2: latency-bound chains, the longest branches of HRNet-W32's regions when run alone), one shared or one auxiliary
+# stream per branch, operands held until the region joins: cfg 4 20.28 -> 24.17 / 23.96 ms, cfg 2 16.15 -> 18.3 ms
+# (scripts/gpu_r04_n.sh) -- every launch moved aside costs two cross-queue event edges in the captured graph, more than it hides.)
 
 
 def _tensors(obj):

@@ -212,8 +212,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
     const int lane0 = threadIdx.x;
     const int h = blockIdx.x % heads;
     // Score arithmetic (as in pk_block.hip's k_attn_bwd): the bias table is kept in units of log2 and the score / dP accumulators START
-    // at -lse / scale and -delta, so P = exp2(fma(acc, scale * log2 e, bias')) and dS = P * acc'; validity comes from the TILE index
-    // (tiles 0..2 hold only real tokens, tile 3 the single token 48), so selects and clamps exist only on the edge tiles.
+    // at -lse / scale and -delta in pass 2 (pass 1 subtracts: no registers to spare), so P = exp2(fma(acc, scale * log2 e, bias')) and
+    // dS = P * acc'; the clamps of the bias index exist only on the edge tiles (tiles 0..2 hold only real tokens).
     constexpr float LOG2E = 1.44269504088896340736f;
     const float scale2 = scale * LOG2E, inv_scale = 1.f / scale;
     for (int i = lane0; i < 169; i += 64) sBias[i] = table[i * heads + h] * LOG2E;
@@ -284,8 +284,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
             const int i = 16 * ci + l16;
             const bool iok = ci < 3 || l16 == 0;
             const int ai = rel_a(iok ? i : 0) + 84 + lz;
-            const float li = sLse[i], di = sDelta[i];
-            const f32x4 li4 = {li, li, li, li}, di4 = {di, di, di, di};
+            // (pass 1 keeps plain subtractions: eight more live registers for the accumulator-start form put this kernel over 256 -- 39 spilled)
+            const float li = -sLse[i] * scale2, di = -sDelta[i];
             bf16x8 qfi[DK], ofi[DK];
 #pragma unroll
             for (int ks = 0; ks < DK; ++ks) {
@@ -301,7 +301,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     const int cj = 2 * s + u;
-                    f32x4 sc = li4, dp = di4;
+                    f32x4 sc = zero, dp = zero;
 #pragma unroll
                     for (int ks = 0; ks < DK; ++ks) {
                         sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(lds_frag(sK, 16 * cj + l16, RP, 32 * ks + g4 * 8), qfi[ks], sc, 0, 0, 0);
@@ -309,10 +309,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool jv = cj < 3 || (g4 == 0 && r == 0);
-                        const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], scale2, sBias[ai - (cj < 3 ? a4[cj][r] : max(a4[cj][r], 0))]));
+                        const bool jv = a4[cj][r] >= 0;        // (the tile-index form of this test costs 37 spilled registers here)
+                        const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], scale2, sBias[ai - (cj < 3 ? a4[cj][r] : max(a4[cj][r], 0))]) - li);
                         const float pv = (iok && jv) ? ev : 0.f;      // select after the fact: straight-line code
-                        ds[u][r] = pv * dp[r];
+                        ds[u][r] = pv * (dp[r] - di);
                         dsum[ci][cj][r] += ds[u][r];
                     }
                 }
@@ -355,7 +355,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DK == 1
                     }
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const bool iv = ci < 3 || (g4 == 0 && r == 0);
+                        const bool iv = a4[ci][r] >= 0;
                         const float ev = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[r], scale2, sBias[(ci < 3 ? a4[ci][r] : max(a4[ci][r], 0)) + ajn]));
                         const float pv = (jok && iv) ? ev : 0.f;
                         pp[u][r] = pv;

@@ -1265,6 +1265,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
     __shared__ __attribute__((aligned(16))) int sA[64];                        // A(t) = 13 (t / 7) + t % 7 of token t, -1 for the tile padding
     __shared__ float sBias[HEADS][176];
     __shared__ __attribute__((aligned(16))) float sLse[4][64], sDelta[4][64];
+    // LayerNorm statistics and pixel rows of the window's tokens, parked until phase 2 (12 registers that were live through both passes:
+    // the kernel sits at the 256-register limit, 10 of them spilled to scratch before)
+    __shared__ float sMean[4][64], sRstd[4][64];
+    __shared__ int sRow[4][64];
     __shared__ float sTab[4][HEADS][192];                                      // rel-pos-bias gradient of this wave: entry e owned by lane e % 64
     // dS of the current (window, head), folded onto sTab once per window.  FOLD_PAD floats of slack on both sides: the fold reads (and
     // masks) words up to 294 before wave 0's tile and 293 after wave 3's -- they stay inside this array whatever the LDS layout is.
@@ -1307,7 +1311,6 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
     for (int w = blockIdx.x * 4 + wave; w < p.n_windows; w += gridDim.x * 4) {
         const int lane = opaque_lane<true>(lane_), i16 = lane & 15, g = lane >> 4;
         int row[4];
-        float mean[4], rstd[4];
         // du = dqkv W_qkv, accumulated tile by tile from the packed dq / dk / dv fragments as the passes produce them: the lane that packs
         // the 8 channels 32 kq + 8g .. of token 16t + i16 for the store is the lane whose B operand they are (no read-back, no transpose)
         f32x4 du[4][NCT];
@@ -1343,7 +1346,13 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
                 }
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
-                    ln_row<NK>(xr[t], gam, bet, inv_c, p.eps, uf[t], mean[t], rstd[t]);
+                    float mean_t, rstd_t;
+                    ln_row<NK>(xr[t], gam, bet, inv_c, p.eps, uf[t], mean_t, rstd_t);
+                    if (g == 0) {
+                        sMean[wave][16 * t + i16] = mean_t;
+                        sRstd[wave][16 * t + i16] = rstd_t;
+                        sRow[wave][16 * t + i16] = row[t];
+                    }
                     scale_rows<NK>(dyr[t], sc, gf[t]);
                     if (row[t] < 0) {
 #pragma unroll
@@ -1575,18 +1584,21 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
         // ================= phase 2: LayerNorm backward + residual gradient in accumulator layout, one token tile at a time; x and dy
         // of all four tiles are requested up front (one round trip instead of four)
         u32x2 xo4[4][NCT], dyo4[4][NCT];
+        int row2[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) row2[t] = sRow[wave][16 * t + i16];
 #pragma unroll
         for (int t = 0; t < 4; ++t)
 #pragma unroll
             for (int ct = 0; ct < NCT; ++ct) {
-                const unsigned off = row[t] >= 0 ? (unsigned)row[t] * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF;
+                const unsigned off = row2[t] >= 0 ? (unsigned)row2[t] * (unsigned)(C * 2) + (16 * ct + 4 * g) * 2 : OOB_OFF;
                 xo4[t][ct] = __builtin_amdgcn_raw_buffer_load_b64(rx, off, 0, 0);
                 dyo4[t][ct] = __builtin_amdgcn_raw_buffer_load_b64(rg, off, 0, 0);
             }
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            const int rw = row[t];
-            const float mu = mean[t], rsd = rstd[t];
+            const int rw = row2[t];
+            const float mu = sMean[wave][16 * t + i16], rsd = sRstd[wave][16 * t + i16];
             const bool valid = rw >= 0;
             f32x4 xh[NCT], gamA[NCT];
             float s1 = 0.f, s2 = 0.f;

@@ -1753,7 +1753,8 @@ static inline int mlp_hidden_slice(int C) {          // hidden units per blockId
     static const int env = PK_KNOB("PK_MLP_HS", 0);
     if (env == 32 || env == 64 || (env == 128 && C == 32)) return env;
     // Measured (B = 64): the 128 accumulator registers of HS * C = 4096 hold the kernel at one wave per SIMD (C = 32: 66 us);
-    // half of that (two waves per SIMD) runs the same work in 40 us although every slice recomputes LayerNorm.
+    // half of that (two waves per SIMD) runs the same work in 40 us although every slice recomputes LayerNorm.  (Round 4, with VGPR-form
+    // MFMAs the 128-unit slice needs 255 registers, i.e. two waves per SIMD as well: 15.48-15.51 vs 15.43-15.51 ms per step -- no gain.)
     return C == 32 ? 64 : 32;
 }
 static inline int mlp_row_groups(int M) { return (M + 31) / 32; }

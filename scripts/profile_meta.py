@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Fingerprint of the code a committed profile was taken with: sha256 over the kernel sources and the host modules that decide which
+"""Fingerprint of the code a committed profile was taken with: sha256 over the kernel sources, their build flags and the host modules that decide which
 kernels are launched.  `python scripts/profile_meta.py write <out.json> "<command>"` stores it next to the profile; bench.py recomputes it
 and marks the in-step fields it reads from profiles/ as stale (null) when it differs."""
 import glob
@@ -14,7 +14,7 @@ PKG = os.path.join(ROOT, "infantposeestimation_gaussianbias_amd")
 
 def fingerprint():
     h = hashlib.sha256()
-    files = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")) +
+    files = sorted(glob.glob(os.path.join(PKG, "csrc", "*.hip")) + glob.glob(os.path.join(PKG, "csrc", "*.h")) + [os.path.join(PKG, "csrc", "Makefile")] +
                    [os.path.join(PKG, f) for f in ("nnops.py", "exchange.py", "dispatch.py", "engine.py")] +
                    glob.glob(os.path.join(PKG, "models", "*.py")))
     for f in files:

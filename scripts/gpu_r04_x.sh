@@ -1,6 +1,5 @@
 #!/bin/bash
-# round 4, call x: k_mlp_fwd<32> with the weight fragments read from LDS inside the loop (106 registers, 4 waves per SIMD) instead of
-# hoisted into registers (190, 2 waves) -- isolated time through the bench probe, then step A/B (B = previous build)
+# round 4, call x: grid / occupancy experiments on the fused MLP kernels -- parity, isolated k_mlp_fwd<32> time through the bench probe, step A/B (B = previous build)
 set -o pipefail
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"

@@ -437,6 +437,7 @@ __global__ void __launch_bounds__(256) k_relbias_reduce(const float* __restrict_
 }
 
 extern "C" int pk_window_attn_bwd_groups(int n_windows, int heads) {
+    if (n_windows <= 0 || heads <= 0) return 0;
     // One 64-lane workgroup per (window-group, head).  The kernel holds 2 waves per SIMD (2048 on the chip): give every
     // workgroup ceil(total / 2048) windows so the whole problem is resident at once and no workgroup walks more than that.
     const long total = (long)n_windows * heads;

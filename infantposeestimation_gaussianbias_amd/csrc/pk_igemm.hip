@@ -2670,6 +2670,7 @@ static int wgrad4_slices(int rows, int N, int Cin, int kind) {
     return s < 1 ? 1 : s;
 }
 extern "C" int pk_wgrad_slices(int M, int N, int Cin, int ksize, int stride, int Hs, int Ws, int flags) {
+    if (M <= 0 || N <= 0 || Cin <= 0 || ksize <= 0) return 0;          // (a size query must not divide by a zero tile count)
     const int kind = wgrad4_kind(N, Cin, ksize, stride, Hs, Ws, flags);
     if (kind) return wgrad4_slices(wgrad4_rows(M, Hs, Ws, kind), N, Cin, kind);
     return wgrad_slices_old(M, N, Cin, ksize * ksize);

@@ -25,6 +25,13 @@ def _chk(t, dtype=F32, name="tensor"):
 _LUT_CACHE = {}
 
 
+def _call_if(n, name, *args):
+    """Launch unless the batch is empty: the reference's tensor code returns empty results for B = 0 (a frame without detections), and a
+    zero-size grid is a launch error.  Nothing is computed on the host either way: the outputs are already the right (empty) shape."""
+    if n > 0:
+        call(name, *args)
+
+
 def _patch_lut(sigma: float, device):
     """Host-built LUT of the reference's float32 patch (datasets/coco_dataset.py:227-233), indexed by d²."""
     key = (float(sigma), str(device))
@@ -51,7 +58,7 @@ def gaussian_target(keypoints, visible, input_size, heatmap_size, sigma):
     lut, n, c = _patch_lut(float(sigma), kp.device)
     target = torch.empty(B, K, hh, wh, dtype=F32, device=kp.device)
     weight = torch.empty(B, K, 1, dtype=F32, device=kp.device)
-    call("pk_gaussian_target", kp, vis, lut, lut.numel(), target, weight, B, K, hh, wh,
+    _call_if(B * K, "pk_gaussian_target", kp, vis, lut, lut.numel(), target, weight, B, K, hh, wh,
          float(input_size[0]) / float(heatmap_size[0]), float(input_size[1]) / float(heatmap_size[1]), float(sigma) * 3, n, c,
          stream_ptr())
     return target, weight
@@ -63,7 +70,7 @@ def dense_target(keypoints, visible, input_size_hw, heatmap_size_hw, sigma):
     hh, hw = int(heatmap_size_hw[0]), int(heatmap_size_hw[1])
     hm = torch.empty(B, K, hh, hw, dtype=F32, device=kp.device)
     w = torch.empty(B, K, dtype=F32, device=kp.device)
-    call("pk_dense_target", kp, vis, hm, w, B, K, hh, hw, float(np.float32(hw / input_size_hw[1])),
+    _call_if(B * K, "pk_dense_target", kp, vis, hm, w, B, K, hh, hw, float(np.float32(hw / input_size_hw[1])),
          float(np.float32(hh / input_size_hw[0])), float(sigma), stream_ptr())
     return hm, w
 
@@ -76,7 +83,7 @@ def argmax_decode(heatmaps, mode=0):
     idx = torch.empty(B, K, dtype=I32, device=hm.device)
     mv = torch.empty(B, K, dtype=F32, device=hm.device)
     co = torch.empty(B, K, 2, dtype=F32, device=hm.device)
-    call("pk_argmax_decode", hm, idx, mv, co, B * K, H, W, int(mode), stream_ptr())
+    _call_if(B * K, "pk_argmax_decode", hm, idx, mv, co, B * K, H, W, int(mode), stream_ptr())
     return idx, mv, co
 
 
@@ -86,7 +93,7 @@ def softargmax_refine_decode(heatmaps, offsets, alpha_param, fusion_weight_param
     off = None if offsets is None else _chk(offsets, name="offsets")
     co = torch.empty(B, K, 2, dtype=F32, device=hm.device)
     sc = torch.empty(B, K, dtype=F32, device=hm.device)
-    call("pk_softargmax_refine_decode", hm, off, _chk(alpha_param.reshape(1)), None if off is None else _chk(fusion_weight_param.reshape(1)),
+    _call_if(B * K, "pk_softargmax_refine_decode", hm, off, _chk(alpha_param.reshape(1)), None if off is None else _chk(fusion_weight_param.reshape(1)),
          co, sc, B * K, H, W, int(radius), stream_ptr())
     return co, sc
 
@@ -95,14 +102,14 @@ def window_refine(heatmaps, coords, window=5):
     hm, c = _chk(heatmaps), _chk(coords)
     B, K, H, W = hm.shape
     out = torch.empty_like(c)
-    call("pk_window_refine", hm, c, out, B * K, H, W, int(window), stream_ptr())
+    _call_if(B * K, "pk_window_refine", hm, c, out, B * K, H, W, int(window), stream_ptr())
     return out
 
 
 def fused_blend(hp, maxvals, regression, sx, sy, reg_scale):
     hp = _chk(hp)
     out = torch.empty_like(hp)
-    call("pk_fused_blend", hp, None if maxvals is None else _chk(maxvals), None if regression is None else _chk(regression), out,
+    _call_if(hp.shape[0] * hp.shape[1], "pk_fused_blend", hp, None if maxvals is None else _chk(maxvals), None if regression is None else _chk(regression), out,
          hp.shape[0] * hp.shape[1], float(sx), float(sy), float(reg_scale), stream_ptr())
     return out
 
@@ -111,7 +118,7 @@ def affine_coords(coords, center, scale, mul_x, mul_y, mask_maxvals=None, thresh
     c = _chk(coords)
     B, K = c.shape[:2]
     out = torch.empty_like(c)
-    call("pk_affine_coords", c, _chk(center), _chk(scale), out, B, K, float(mul_x), float(mul_y),
+    _call_if(B * K, "pk_affine_coords", c, _chk(center), _chk(scale), out, B, K, float(mul_x), float(mul_y),
          None if mask_maxvals is None else _chk(mask_maxvals), float(threshold), stream_ptr())
     return out
 
@@ -122,7 +129,7 @@ def pose_records(keypoints, scores):
     B, K = sc.shape
     rec = torch.empty(B, K, 3, dtype=F32, device=kp.device)
     inst = torch.empty(B, dtype=F32, device=kp.device)
-    call("pk_pose_records", kp, sc, rec, inst, B, K, stream_ptr())
+    _call_if(B * K, "pk_pose_records", kp, sc, rec, inst, B, K, stream_ptr())
     return rec, inst
 
 
@@ -130,7 +137,7 @@ def flip_merge(hm, hm_from_flipped, partner):
     a, b = _chk(hm), _chk(hm_from_flipped)
     B, K, H, W = a.shape
     out = torch.empty_like(a)
-    call("pk_flip_merge", a, b, _chk(partner, I32), out, B, K, H, W, stream_ptr())
+    _call_if(B * K, "pk_flip_merge", a, b, _chk(partner, I32), out, B, K, H, W, stream_ptr())
     return out
 
 
@@ -388,7 +395,7 @@ def nms_pose(preds, maxvals, distance_threshold=5.0):
     B, K, _ = preds.shape
     out = torch.empty_like(preds)
     keep = torch.empty(B, K, dtype=torch.uint8, device=preds.device)
-    call("pk_nms_pose", preds, maxvals, out, keep, B, K, float(distance_threshold), stream_ptr())
+    _call_if(B * K, "pk_nms_pose", preds, maxvals, out, keep, B, K, float(distance_threshold), stream_ptr())
     return out, keep.bool().view(B, K, 1)
 
 

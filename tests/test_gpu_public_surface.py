@@ -185,3 +185,38 @@ def test_heatmap_head_deconv_stack_vs_reference(golden):
         assert rel_err(C(head.eval()(x.detach())), z["y_eval"]) < 3e-2
     with pytest.raises(ValueError):
         HeatmapHead(32, 17, num_deconv_layers=1, num_deconv_filters=(32,), num_deconv_kernels=(3,))
+
+
+def test_empty_batches_give_empty_results_like_the_reference():
+    """A frame without detections: the reference's tensor code (utils/postprocess.py:10-34, 139-184, 241-303; T1 per sample) returns empty
+    (0, K, ...) results for B = 0.  Ours must too -- a zero-size grid would be a launch error -- and with the reference's shapes."""
+    from infantposeestimation_gaussianbias_amd import hipops
+    from infantposeestimation_gaussianbias_amd.utils import postprocess as pp
+    K, H, W = 17, 64, 48
+    hm = torch.zeros(0, K, H, W, device=DEV)
+    preds, mv = pp.get_max_preds(hm)
+    assert tuple(preds.shape) == (0, K, 2) and tuple(mv.shape) == (0, K, 1) and preds.dtype == torch.float32
+    preds, mv = pp.get_max_preds_with_subpixel(hm)
+    assert tuple(preds.shape) == (0, K, 2) and tuple(mv.shape) == (0, K, 1)
+    assert tuple(pp.coordinate_refinement(hm, preds).shape) == (0, K, 2)
+    p2, mask = pp.filter_low_confidence(preds, mv)
+    assert tuple(p2.shape) == (0, K, 2) and tuple(mask.shape) == (0, K, 1)
+    p3, keep = pp.nms_pose(preds, mv)
+    assert tuple(p3.shape) == (0, K, 2) and tuple(keep.shape) == (0, K, 1) and keep.dtype == torch.bool
+    c, s = torch.zeros(0, 2, device=DEV), torch.zeros(0, 2, device=DEV)
+    assert tuple(pp.transform_preds(preds, c, s, [640, 480]).shape) == (0, K, 2)
+    assert tuple(pp.heatmap_to_image_coords(preds, c, s, (192, 256), (48, 64)).shape) == (0, K, 2)
+    co, sc = hipops.softargmax_refine_decode(hm, None, torch.ones(1, device=DEV), None)
+    assert tuple(co.shape) == (0, K, 2) and tuple(sc.shape) == (0, K)
+    rec, inst = hipops.pose_records(preds, mv.squeeze(-1))
+    assert tuple(rec.shape) == (0, K, 3) and tuple(inst.shape) == (0,)
+    t, w = hipops.gaussian_target(torch.zeros(0, K, 2, device=DEV), torch.zeros(0, K, device=DEV), (192, 256), (48, 64), 2.0)
+    assert tuple(t.shape) == (0, K, 64, 48) and tuple(w.shape) == (0, K, 1)
+    out = hipops.flip_merge(hm, hm, torch.arange(K, dtype=torch.int32, device=DEV))
+    assert tuple(out.shape) == (0, K, H, W)
+    # one real sample next to it still decodes as before (the early return is only for the empty case)
+    one = torch.zeros(1, K, H, W, device=DEV)
+    one[0, :, 10, 7] = 1.0
+    preds1, mv1 = pp.get_max_preds(one)
+    assert torch.equal(preds1[0, 0].cpu(), torch.tensor([7.0, 10.0])) and float(mv1[0, 0, 0]) == 1.0
+    torch.cuda.synchronize()

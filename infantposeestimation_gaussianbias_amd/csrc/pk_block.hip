@@ -1656,7 +1656,10 @@ __global__ void __launch_bounds__(256, 2) k_attn_bwd(AttnArgs p, float* __restri
 }
 
 static inline int attn_blocks(int n_windows) {
-    static const int cap = PK_KNOB("PK_ATTN_WGS", 1024);
+    // one 4-wave workgroup per CU, each wave walking ~4 windows (B = 64): 1 024 workgroups (two rounds of two per CU, one window per wave)
+    // cost the step 0.13 ms more (15.49-15.56 vs 15.38 ms, three alternating runs; 128 / 192 / 512 / 2 048: 15.37 / 15.41 / 15.37 / 15.49) --
+    // a quarter of the weight prologues, and room on every CU for the other branches' workgroups
+    static const int cap = PK_KNOB("PK_ATTN_WGS", 256);
     const int need = (n_windows + 3) / 4;
     return need < cap ? (need < 1 ? 1 : need) : cap;
 }
@@ -1771,11 +1774,23 @@ static inline int mlp_blocks(int M, int target) {
     const int need = (mlp_row_groups(M) + 3) / 4;
     return need < target ? (need < 1 ? 1 : need) : target;
 }
-extern "C" int pk_ln_mlp_dx_blocks(int M, int C) { return mlp_blocks(M, 512); }
+static inline int mlp_dx_target(int C) {
+    static const int t32 = PK_KNOB("PK_MLP_DX32_WGS", 512), t64 = PK_KNOB("PK_MLP_DX64_WGS", 512);
+    return C == 32 ? t32 : t64;
+}
+static inline int mlp_fwd_target(int C) {
+    static const int t32 = PK_KNOB("PK_MLP_FWD32_WGS", 512), t64 = PK_KNOB("PK_MLP_FWD64_WGS", 512);
+    return C == 32 ? t32 : t64;
+}
+static inline int mlp_dw_target(int C) {
+    static const int t32 = PK_KNOB("PK_MLP_DW32_WGS", 256), t64 = PK_KNOB("PK_MLP_DW64_WGS", 64);
+    return C == 32 ? t32 : t64;
+}
+extern "C" int pk_ln_mlp_dx_blocks(int M, int C) { return mlp_blocks(M, mlp_dx_target(C)); }
 // (fewer, longer-lived workgroups: each one stages its weight slice and ends with a 4-phase slab reduction; 256 x slices
 // workgroups beat 512 and 1024 at every slice width)
 // workgroups beat 512 and 1024 at every slice width; C = 64 with its 8 slices: 64 x 8 = 38 us, 128 x 8 = 46 us, 256 x 8 = 67 us)
-extern "C" int pk_ln_mlp_dw_blocks(int M, int C) { return mlp_blocks(M, C == 32 ? 256 : 64); }
+extern "C" int pk_ln_mlp_dw_blocks(int M, int C) { return mlp_blocks(M, mlp_dw_target(C)); }
 
 static int mlp_check(const char* who, const MlpArgs& a, int C) {
     PK_SUPPORTED(C == 32 || C == 64, "%s: C=%d (the fused MLP half is built for C = 32 / 64)", who, C);
@@ -1795,7 +1810,7 @@ extern "C" int pk_ln_mlp_fwd(const void* x, const float* gamma, const float* bet
     int rc = mlp_check("pk_ln_mlp_fwd", a, C);
     if (rc) return rc;
     PK_REQUIRE(w1 && w2 && b2 && y, "pk_ln_mlp_fwd: null pointer");
-    const dim3 grid(mlp_blocks(M, 512)), block(256);
+    const dim3 grid(mlp_blocks(M, mlp_fwd_target(C))), block(256);
     if (C == 32) hipLaunchKernelGGL(k_mlp_fwd<32>, grid, block, 0, (hipStream_t)stream, a);
     else hipLaunchKernelGGL(k_mlp_fwd<64>, grid, block, 0, (hipStream_t)stream, a);
     return pk_launch_status("pk_ln_mlp_fwd");

@@ -441,7 +441,8 @@ extern "C" int pk_window_attn_bwd_groups(int n_windows, int heads) {
     // One 64-lane workgroup per (window-group, head).  The kernel holds 2 waves per SIMD (2048 on the chip): give every
     // workgroup ceil(total / 2048) windows so the whole problem is resident at once and no workgroup walks more than that.
     const long total = (long)n_windows * heads;
-    const int wpg = (int)((total + 2047) / 2048);
+    static const int slots = PK_KNOB("PK_WATTN_BWD_SLOTS", 2048);
+    const int wpg = (int)((total + slots - 1) / slots);
     const int per_head = (n_windows + wpg - 1) / wpg;
     return per_head * heads;
 }

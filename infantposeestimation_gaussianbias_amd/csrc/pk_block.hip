@@ -1783,7 +1783,8 @@ static inline int mlp_fwd_target(int C) {
     return C == 32 ? t32 : t64;
 }
 static inline int mlp_dw_target(int C) {
-    static const int t32 = PK_KNOB("PK_MLP_DW32_WGS", 256), t64 = PK_KNOB("PK_MLP_DW64_WGS", 64);
+    // (C = 64: 32 x 8 slices = one workgroup per CU; 64 x 8 ran 38 us in isolation and the step 0.07 ms slower, see PK_ATTN_WGS)
+    static const int t32 = PK_KNOB("PK_MLP_DW32_WGS", 256), t64 = PK_KNOB("PK_MLP_DW64_WGS", 32);
     return C == 32 ? t32 : t64;
 }
 extern "C" int pk_ln_mlp_dx_blocks(int M, int C) { return mlp_blocks(M, mlp_dx_target(C)); }

@@ -1,5 +1,7 @@
 #!/bin/bash
 # round 4, call z: grid sizes on the TUNING build -- persistent workgroups per CU of the halo conv kernel (cfg 4's branches 0 / 1 are chains of it)
+# (the TUNING library: copy csrc/ + include/ to a scratch directory, `make TUNING=1` there, copy its libposekernels.so to
+#  infantposeestimation_gaussianbias_amd/csrc/libposekernels_tuning.so before the gpurun call; the release library ignores these knobs)
 set -o pipefail
 mkdir -p gpurun_out
 cd "$GRAFT_REPO_ROOT"
